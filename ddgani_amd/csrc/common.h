@@ -1,0 +1,61 @@
+// Shared device/host helpers for libddgani_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ddgani.h"
+
+#define DDG_CHECK_LAUNCH()                                    \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return DDG_E_LAUNCH; \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline __host__ __device__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. 2011): one call -> 4 x uint32.
+// counter = (idx_lo, idx_hi, stream_lo, stream_hi), key = seed.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// uniform in (0,1]: never 0, so log() is finite
+__device__ __forceinline__ float u32_to_unit(uint32_t u) { return ((u >> 8) + 1) * (1.0f / 16777216.0f); }
+
+// 4 standard normals for element group `idx` of random stream `stream_id`
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_id, uint64_t idx) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    float u0 = u32_to_unit(r[0]), u1 = u32_to_unit(r[1]), u2 = u32_to_unit(r[2]), u3 = u32_to_unit(r[3]);
+    float ra = sqrtf(-2.0f * __logf(u0)), rb = sqrtf(-2.0f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u1, &s0, &c0);
+    __sincosf(6.283185307179586f * u3, &s1, &c1);
+    f32x4 o;
+    o.x = ra * c0; o.y = ra * s0; o.z = rb * c1; o.w = rb * s1;
+    return o;
+}
+
+// 4 uniforms in (0,1] for element group idx
+__device__ __forceinline__ f32x4 philox_uniform4(uint64_t seed, uint64_t stream_id, uint64_t idx) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    f32x4 o;
+    o.x = u32_to_unit(r[0]); o.y = u32_to_unit(r[1]); o.z = u32_to_unit(r[2]); o.w = u32_to_unit(r[3]);
+    return o;
+}

@@ -1,0 +1,297 @@
+// HBM-bound passes of the sampler: noise schedule, forward noising, fused reverse step,
+// per-field head, mask-merge, BatchNorm finalize.  gfx950 only.
+//
+// Reference functions restated here (relative to the reference tree):
+//   Diffusion_setting.initialize   model/Diffusion.py:93-108
+//   forward_diffusion / get_xt     model/Diffusion.py:391-403
+//   G_D_onestep (after G call)     model/Diffusion.py:415-424
+//   Generator_x0 head              model/Diffusion.py:188-201
+//   mask-merge + re-softmax        model/Diffusion.py:598, :606-615
+#include <math.h>
+#include "common.h"
+
+extern "C" int ddg_version(void) { return 100; }
+
+extern "C" const char *ddg_error_string(int code) {
+    switch (code) {
+        case DDG_OK: return "ok";
+        case DDG_E_ARG: return "bad argument";
+        case DDG_E_UNSUPPORTED: return "unsupported shape";
+        case DDG_E_WORKSPACE: return "workspace too small";
+        case DDG_E_LAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3 schedule (host).  Same fp32 operation order as torch: linspace -> beta[0]=0 -> 1-beta ->
+// sqrt -> cumprod -> sqrt.  torch.linspace(fp32) computes start + step*i for the first half and
+// end - step*(steps-1-i) for the second half, step = (end-start)/(steps-1) in fp32.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ddg_schedule(int T, float *o) {
+    if (T < 1 || !o) return DDG_E_ARG;
+    float *betas = o, *alphas = o + T, *sa = o + 2 * T, *obsa = o + 3 * T, *sb = o + 4 * T, *ac = o + 5 * T,
+          *sac = o + 6 * T, *s1mac = o + 7 * T;
+    const float start = 1e-4f, end = 2e-2f;
+    if (T == 1) {
+        betas[0] = start;
+    } else {
+        const float step = (end - start) / (float)(T - 1);
+        const int half = T / 2;
+        for (int i = 0; i < T; ++i) {
+            volatile float v = (i < half) ? start + step * (float)i : end - step * (float)(T - 1 - i);
+            betas[i] = v;
+        }
+    }
+    betas[0] = 0.f;
+    double cp = 1.0;   // torch.cumprod accumulates fp32 inputs in double on the CPU
+    for (int i = 0; i < T; ++i) {
+        alphas[i] = 1.f - betas[i];
+        sa[i] = sqrtf(alphas[i]);
+        obsa[i] = 1.f / sa[i];
+        sb[i] = sqrtf(betas[i]);
+        cp *= (double)alphas[i];
+        ac[i] = (float)cp;
+        sac[i] = sqrtf(ac[i]);
+        s1mac[i] = sqrtf(1.f - ac[i]);
+    }
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5 forward noising
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+__global__ void k_forward_noise_uniform(const float *__restrict__ x0, const float *__restrict__ eps,
+                                        float ca, float cb, uint64_t seed, uint64_t stream_id,
+                                        float *__restrict__ xt, float *__restrict__ eps_out, int64_t n) {
+    const int64_t ngroups = (n + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = g * 4;
+        if (e0 + 3 < n) {
+            f32x4 xv = *reinterpret_cast<const f32x4 *>(x0 + e0);
+            f32x4 ev = eps ? *reinterpret_cast<const f32x4 *>(eps + e0) : philox_normal4(seed, stream_id, (uint64_t)g);
+            f32x4 r;
+            r.x = ca * xv.x + cb * ev.x; r.y = ca * xv.y + cb * ev.y;
+            r.z = ca * xv.z + cb * ev.z; r.w = ca * xv.w + cb * ev.w;
+            *reinterpret_cast<f32x4 *>(xt + e0) = r;
+            if (eps_out) *reinterpret_cast<f32x4 *>(eps_out + e0) = ev;
+        } else {
+            f32x4 ev4 = eps ? f32x4{0, 0, 0, 0} : philox_normal4(seed, stream_id, (uint64_t)g);
+            for (int c = 0; c < 4 && e0 + c < n; ++c) {
+                float ev = eps ? eps[e0 + c] : ev4[c];
+                xt[e0 + c] = ca * x0[e0 + c] + cb * ev;
+                if (eps_out) eps_out[e0 + c] = ev;
+            }
+        }
+    }
+}
+
+__global__ void k_forward_noise_rows(const float *__restrict__ x0, const float *__restrict__ eps,
+                                     const int64_t *__restrict__ t, const float *__restrict__ sched, int T,
+                                     uint64_t seed, uint64_t stream_id, float *__restrict__ xt,
+                                     float *__restrict__ eps_out, int64_t rows, int D) {
+    const int64_t n = rows * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / D;
+        const int ti = (int)t[r] - 1;
+        const float ca = sched[6 * T + ti], cb = sched[7 * T + ti];
+        float ev;
+        if (eps) ev = eps[e];
+        else ev = philox_normal4(seed, stream_id, (uint64_t)(e >> 2))[e & 3];
+        xt[e] = ca * x0[e] + cb * ev;
+        if (eps_out) eps_out[e] = ev;
+    }
+}
+
+static inline int ew_grid(int64_t work_items, int block) {
+    int64_t g = ceil_div64(work_items, block);
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int ddg_forward_noise(const float *x0, const float *eps, const int64_t *t, int t_uniform,
+                                 const float *sched, int T, uint64_t seed, uint64_t stream_id, float *x_t,
+                                 float *eps_out, int64_t rows, int D, void *stream) {
+    if (!x0 || !x_t || rows < 0 || D < 1 || T < 1) return DDG_E_ARG;
+    if (rows == 0) return DDG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = rows * D;
+    if (t) {
+        if (!sched) return DDG_E_ARG;
+        k_forward_noise_rows<<<ew_grid(n, 256), 256, 0, s>>>(x0, eps, t, sched, T, seed, stream_id, x_t, eps_out, rows, D);
+    } else {
+        if (t_uniform < 1 || t_uniform > T) return DDG_E_ARG;
+        float h[8 * 64];
+        float *hs = h;
+        float *dyn = nullptr;
+        if (T > 64) { dyn = (float *)malloc(sizeof(float) * 8 * (size_t)T); hs = dyn; }
+        ddg_schedule(T, hs);
+        const float ca = hs[6 * T + t_uniform - 1], cb = hs[7 * T + t_uniform - 1];
+        if (dyn) free(dyn);
+        k_forward_noise_uniform<<<ew_grid((n + 3) / 4, 256), 256, 0, s>>>(x0, eps, ca, cb, seed, stream_id, x_t, eps_out, n);
+    }
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 fused reverse step: posterior mean + noise + observed-cell re-noising + mask-merge.
+// One HBM pass: reads x_t, x, M, pred (+z when explicit), writes x_{t-1}.
+// ---------------------------------------------------------------------------------------------
+struct RevCoef { float c1, c2, c3, den, sacm1, s1mm1; };
+
+__device__ __forceinline__ float rev_one(float xt, float x, float M, float p, float z, const RevCoef &k) {
+    const float gm = (k.c1 * p + k.c2 * xt) / k.den;
+    const float gs = (k.c3 * z) / k.den;
+    const float g = gm + gs;
+    const float o = k.sacm1 * x + k.s1mm1 * z;
+    return M * o + (1.f - M) * g;
+}
+
+__global__ void k_reverse_step(const float *__restrict__ xt, const float *__restrict__ x, const float *__restrict__ M,
+                               const float *__restrict__ pred, const float *__restrict__ z, RevCoef k, uint64_t seed,
+                               uint64_t stream_id, float *__restrict__ out, int64_t n) {
+    const int64_t ngroups = (n + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e0 = g * 4;
+        if (e0 + 3 < n) {
+            f32x4 a = *reinterpret_cast<const f32x4 *>(xt + e0);
+            f32x4 b = *reinterpret_cast<const f32x4 *>(x + e0);
+            f32x4 m = *reinterpret_cast<const f32x4 *>(M + e0);
+            f32x4 p = *reinterpret_cast<const f32x4 *>(pred + e0);
+            f32x4 zz = z ? *reinterpret_cast<const f32x4 *>(z + e0) : philox_normal4(seed, stream_id, (uint64_t)g);
+            f32x4 r;
+            r.x = rev_one(a.x, b.x, m.x, p.x, zz.x, k); r.y = rev_one(a.y, b.y, m.y, p.y, zz.y, k);
+            r.z = rev_one(a.z, b.z, m.z, p.z, zz.z, k); r.w = rev_one(a.w, b.w, m.w, p.w, zz.w, k);
+            *reinterpret_cast<f32x4 *>(out + e0) = r;
+        } else {
+            f32x4 z4 = z ? f32x4{0, 0, 0, 0} : philox_normal4(seed, stream_id, (uint64_t)g);
+            for (int c = 0; c < 4 && e0 + c < n; ++c)
+                out[e0 + c] = rev_one(xt[e0 + c], x[e0 + c], M[e0 + c], pred[e0 + c], z ? z[e0 + c] : z4[c], k);
+        }
+    }
+}
+
+extern "C" int ddg_reverse_step(const float *x_t, const float *x, const float *M, const float *pred, const float *z,
+                                const float *sh, int T, int t, uint64_t seed, uint64_t stream_id, float *out,
+                                int64_t rows, int D, void *stream) {
+    if (!x_t || !x || !M || !pred || !sh || !out || rows < 0 || D < 1) return DDG_E_ARG;
+    if (t < 2 || t > T) return DDG_E_ARG;
+    if (rows == 0) return DDG_OK;
+    const float *betas = sh, *sa = sh + 2 * T, *ac = sh + 5 * T, *sac = sh + 6 * T, *s1mac = sh + 7 * T;
+    // coefficient products in the reference's fp32 association (model/Diffusion.py:415-421)
+    RevCoef k;
+    volatile float one_m_acm1 = 1.f - ac[t - 2];
+    volatile float c1 = sac[t - 2] * betas[t - 1];
+    volatile float c2 = sa[t - 1] * one_m_acm1;
+    volatile float c3 = one_m_acm1 * betas[t - 1];
+    volatile float den = 1.f - ac[t - 1];
+    k.c1 = c1; k.c2 = c2; k.c3 = c3; k.den = den; k.sacm1 = sac[t - 2]; k.s1mm1 = s1mac[t - 2];
+    const int64_t n = rows * D;
+    k_reverse_step<<<ew_grid((n + 3) / 4, 256), 256, 0, (hipStream_t)stream>>>(x_t, x, M, pred, z, k, seed, stream_id, out, n);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6 head / a9 mask-merge: a block stages ROWS_PB rows in LDS (coalesced), one thread per
+// (row, field) applies sigmoid / softmax over the field's block, then the rows go back coalesced.
+// ---------------------------------------------------------------------------------------------
+template <bool MERGE>
+__global__ void k_head_merge(const float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ M,
+                             const int32_t *__restrict__ offsets, const uint8_t *__restrict__ is_cat, int C,
+                             float *__restrict__ out, int64_t rows, int D, int rows_pb) {
+    extern __shared__ float tile[];
+    const int64_t nblk = ceil_div64(rows, rows_pb);
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t r0 = blk * rows_pb;
+        const int nr = (int)((rows - r0 < rows_pb) ? rows - r0 : rows_pb);
+        const int64_t base = r0 * D;
+        const int nel = nr * D;
+        for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+            float v = y[base + i];
+            if (MERGE) {
+                const float m = M[base + i];
+                v = m * x[base + i] + (1.f - m) * v;
+            }
+            tile[i] = v;
+        }
+        __syncthreads();
+        for (int w = threadIdx.x; w < nr * C; w += blockDim.x) {
+            const int r = w / C, f = w - r * C;
+            const int a = offsets[f], b = offsets[f + 1];
+            float *p = tile + r * D;
+            if (is_cat[f]) {
+                float mx = p[a];
+                for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
+                float s = 0.f;
+                for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
+                for (int j = a; j < b; ++j) p[j] = p[j] / s;
+            } else if (!MERGE) {
+                for (int j = a; j < b; ++j) p[j] = 1.f / (1.f + expf(-p[j]));
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nel; i += blockDim.x) out[base + i] = tile[i];
+        __syncthreads();
+    }
+}
+
+static int launch_head_merge(bool merge, const float *y, const float *x, const float *M, const int32_t *offsets,
+                             const uint8_t *is_cat, int C, float *out, int64_t rows, int D, void *stream) {
+    if (!y || !offsets || !is_cat || !out || rows < 0 || D < 1 || C < 1) return DDG_E_ARG;
+    if (merge && (!x || !M)) return DDG_E_ARG;
+    if (rows == 0) return DDG_OK;
+    int rows_pb = 8192 / D;            // <= 32 KiB of LDS
+    if (rows_pb < 1) return DDG_E_UNSUPPORTED;
+    if (rows_pb > 64) rows_pb = 64;
+    const size_t lds = (size_t)rows_pb * D * sizeof(float);
+    int64_t nblk = ceil_div64(rows, rows_pb);
+    int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    if (merge)
+        k_head_merge<true><<<grid, 256, lds, (hipStream_t)stream>>>(y, x, M, offsets, is_cat, C, out, rows, D, rows_pb);
+    else
+        k_head_merge<false><<<grid, 256, lds, (hipStream_t)stream>>>(y, x, M, offsets, is_cat, C, out, rows, D, rows_pb);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+extern "C" int ddg_head(const float *y, const int32_t *offsets, const uint8_t *is_cat, int C, float *out,
+                        int64_t rows, int D, void *stream) {
+    return launch_head_merge(false, y, nullptr, nullptr, offsets, is_cat, C, out, rows, D, stream);
+}
+
+extern "C" int ddg_mask_merge(const float *x, const float *M, const float *xhat, const int32_t *offsets,
+                              const uint8_t *is_cat, int C, float *code, int64_t rows, int D, void *stream) {
+    return launch_head_merge(true, xhat, x, M, offsets, is_cat, C, code, rows, D, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm1d train-mode statistics -> per-column scale/shift
+// ---------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(const double *__restrict__ stats, const float *__restrict__ gamma,
+                              const float *__restrict__ beta, double n, float eps, float *__restrict__ scale,
+                              float *__restrict__ shift, int width) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= width) return;
+    const double mean = stats[k] / n;
+    double var = stats[width + k] / n - mean * mean;
+    if (var < 0) var = 0;
+    const double inv = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[k] * inv;
+    scale[k] = (float)sc;
+    shift[k] = (float)((double)beta[k] - mean * sc);
+}
+
+extern "C" int ddg_bn_finalize(const double *stats, const float *gamma, const float *beta, double total_rows,
+                               float eps, float *scale, float *shift, int width, void *stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || width < 1 || total_rows <= 0) return DDG_E_ARG;
+    k_bn_finalize<<<(width + 255) / 256, 256, 0, (hipStream_t)stream>>>(stats, gamma, beta, total_rows, eps, scale, shift, width);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

@@ -1,0 +1,345 @@
+// Dense layers of the denoiser / discriminator on the fp32 MFMA (v_mfma_f32_32x32x2_f32),
+// with the element-wise work of the neighbouring layers fused into the operand load and the
+// BatchNorm column statistics fused into the epilogue.  gfx950 only.
+//
+// Reference ops restated (relative to the reference tree):
+//   Generator_x0.forward           model/Diffusion.py:179-187  (Linear/BatchNorm1d/ReLU/Dropout)
+//   Discriminator_noise_x.forward  model/Discriminator_model.py:105-113
+//
+// Tiling: block = 4 waves (2x2), block tile 128 rows x 128 out-cols, K staged in chunks of 32
+// through double-buffered LDS (rows padded to 36 floats: conflict-free ds_read_b128).  A wave
+// owns a 64x64 sub-tile = 2x2 MFMA tiles (64 accumulator registers).  The K order inside a
+// chunk is permuted (lane half h consumes k = 8u+4h..8u+4h+3) so that every operand fragment
+// is one 16-byte LDS read; A and B use the same permutation, so the dot products are unchanged
+// up to fp32 summation order.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDS_STRIDE 36
+
+struct LinArgs {
+    const float *A, *A2;
+    int in1;
+    const float *W, *bias;
+    const float *emb;
+    const int64_t *t;
+    int t_uniform;
+    const float *scale, *shift;
+    const uint8_t *drop;
+    float drop_p;
+    uint64_t seed, stream_id;
+    float *Y;
+    double *stats;
+    int64_t rows;
+    int in, out;
+};
+
+__device__ __forceinline__ float lin_fetch_a(const LinArgs &p, int64_t row, int k) {
+    // raw element of the (possibly concatenated) A operand
+    if (k < p.in1) return p.A[row * p.in1 + k];
+    return p.A2[row * (int64_t)(p.in - p.in1) + (k - p.in1)];
+}
+
+template <int PRO>
+__device__ __forceinline__ float lin_transform(const LinArgs &p, float a, int64_t row, int k, int trow,
+                                               float keep_scale) {
+    if (PRO == DDG_PRO_ADD_EMB) {
+        return a + p.emb[(int64_t)trow * p.in + k];
+    } else if (PRO == DDG_PRO_EMB_RELU) {
+        return fmaxf(a + p.emb[(int64_t)trow * p.in + k], 0.f);
+    } else if (PRO == DDG_PRO_BN_RELU) {
+        float v = fmaxf(a * p.scale[k] + p.shift[k], 0.f);
+        if (p.drop) {
+            v = p.drop[row * p.in + k] ? v * keep_scale : 0.f;
+        } else if (p.drop_p > 0.f) {
+            const uint64_t e = (uint64_t)row * (uint64_t)p.in + (uint64_t)k;
+            const float u = philox_uniform4(p.seed, p.stream_id, e >> 2)[e & 3];
+            v = (u > p.drop_p) ? v * keep_scale : 0.f;
+        }
+        return v;
+    }
+    return a;
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void k_linear(LinArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_STRIDE];
+    __shared__ double red[4][2][2][32];   // [wave][ct][sum|sumsq][col]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.y * BN;
+    const int nchunks = (p.in + BK - 1) / BK;
+    const int64_t ntiles = ceil_div64(p.rows, BM);
+    const float keep_scale = 1.f / (1.f - p.drop_p);
+
+    double s1[2] = {0, 0}, s2[2] = {0, 0};
+
+    // staging assignment: 128 rows x 8 float4 per operand chunk -> 4 float4 per thread
+    const int st_c4 = tid & 7;          // which float4 of the 32-wide chunk
+    const int st_r = tid >> 3;          // 0..31, rows st_r + 32*i
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * BM;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+        int trows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + st_r + 32 * i;
+            trows[i] = 0;
+            if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
+                trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
+        }
+
+        auto stage = [&](int buf, int chunk) {
+            const int k0 = chunk * BK + st_c4 * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = st_r + 32 * i;
+                const int64_t row = row0 + rl;
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                if (row < p.rows) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + e;
+                        if (k < p.in)
+                            av[e] = lin_transform<PRO>(p, lin_fetch_a(p, row, k), row, k, trows[i], keep_scale);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(&As[buf][rl * LDS_STRIDE + st_c4 * 4]) = av;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                const int n = col0 + rl;
+                if (n < p.out) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + e;
+                        if (k < p.in) bv[e] = p.W[(int64_t)n * p.in + k];
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(&Bs[buf][rl * LDS_STRIDE + st_c4 * 4]) = bv;
+            }
+        };
+
+        stage(0, 0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int cur = c & 1;
+            if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
+            const float *Ab = &As[cur][(wr * 64 + r32) * LDS_STRIDE + 4 * h];
+            const float *Bb = &Bs[cur][(wc * 64 + r32) * LDS_STRIDE + 4 * h];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(Ab + 8 * u);
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(Ab + 32 * LDS_STRIDE + 8 * u);
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(Bb + 8 * u);
+                const f32x4 b1 = *reinterpret_cast<const f32x4 *>(Bb + 32 * LDS_STRIDE + 8 * u);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b1[s], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b0[s], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc[1][1], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+
+        // epilogue: + bias, store (128-byte segments per half-wave), column statistics in fp64
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = col0 + wc * 64 + ct * 32 + r32;
+            const bool cok = col < p.out;
+            const float bj = cok ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int64_t row = row0 + wr * 64 + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (cok && row < p.rows) {
+                        const float v = acc[rt][ct][g] + bj;
+                        p.Y[row * p.out + col] = v;
+                        s1[ct] += (double)v;
+                        s2[ct] += (double)v * (double)v;
+                    }
+                }
+            }
+        }
+    }
+
+    if (p.stats) {   // kernel-uniform
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            double a = s1[ct], b = s2[ct];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            if (h == 0) { red[wid][ct][0][r32] = a; red[wid][ct][1][r32] = b; }
+        }
+        __syncthreads();
+        if (wr == 0 && h == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = col0 + wc * 64 + ct * 32 + r32;
+                if (col < p.out) {
+                    const double a = red[wid][ct][0][r32] + red[wid + 2][ct][0][r32];
+                    const double b = red[wid][ct][1][r32] + red[wid + 2][ct][1][r32];
+                    atomicAdd(&p.stats[col], a);
+                    atomicAdd(&p.stats[p.out + col], b);
+                }
+            }
+        }
+    }
+}
+
+static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
+    const int64_t ntiles = ceil_div64(p.rows, BM);
+    const int ncol = (p.out + BN - 1) / BN;
+    int64_t gx = ntiles;
+    const int64_t cap = (256 * 2 + ncol - 1) / ncol;   // ~2 resident blocks per CU in total
+    if (gx > cap) gx = cap;
+    dim3 grid((unsigned)gx, (unsigned)ncol);
+    switch (prologue) {
+        case DDG_PRO_NONE: k_linear<DDG_PRO_NONE><<<grid, 256, 0, s>>>(p); break;
+        case DDG_PRO_ADD_EMB: k_linear<DDG_PRO_ADD_EMB><<<grid, 256, 0, s>>>(p); break;
+        case DDG_PRO_BN_RELU: k_linear<DDG_PRO_BN_RELU><<<grid, 256, 0, s>>>(p); break;
+        case DDG_PRO_EMB_RELU: k_linear<DDG_PRO_EMB_RELU><<<grid, 256, 0, s>>>(p); break;
+        default: return DDG_E_ARG;
+    }
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+extern "C" int ddg_linear(const float *A, const float *A2, int in1, const float *W, const float *bias, int prologue,
+                          const float *emb, const int64_t *t, int t_uniform, const float *scale, const float *shift,
+                          const uint8_t *drop, float drop_p, uint64_t seed, uint64_t stream_id, float *Y,
+                          double *stats, int64_t rows, int in, int out, void *stream) {
+    if (!A || !W || !bias || !Y || rows < 0 || in < 1 || out < 1) return DDG_E_ARG;
+    if (A2 ? (in1 < 1 || in1 >= in) : (in1 != in)) return DDG_E_ARG;
+    if ((prologue == DDG_PRO_ADD_EMB || prologue == DDG_PRO_EMB_RELU) && !emb) return DDG_E_ARG;
+    if (prologue == DDG_PRO_BN_RELU && (!scale || !shift)) return DDG_E_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return DDG_E_ARG;
+    if (rows == 0) return DDG_OK;
+    LinArgs p;
+    p.A = A; p.A2 = A2; p.in1 = in1; p.W = W; p.bias = bias; p.emb = emb; p.t = t; p.t_uniform = t_uniform;
+    p.scale = scale; p.shift = shift; p.drop = drop; p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
+    p.Y = Y; p.stats = stats; p.rows = rows; p.in = in; p.out = out;
+    return launch_linear(p, prologue, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6 Generator_x0.forward, single-GPU composition
+// workspace: z1 [rows,enc] | z2 [rows,lat] | stats double[2*max] x3 | scale/shift float[max] x 2 x 3
+// (z3 reuses z1; the pre-head logits go straight to `out`)
+// ---------------------------------------------------------------------------------------------
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t ddg_denoiser_workspace_bytes(int64_t rows, int in_dim, int enc_dim, int lat_dim) {
+    (void)in_dim;
+    const size_t mx = (size_t)(enc_dim > lat_dim ? enc_dim : lat_dim);
+    return align256((size_t)rows * enc_dim * 4) + align256((size_t)rows * lat_dim * 4) + 3 * align256(2 * mx * 8) +
+           6 * align256(mx * 4);
+}
+
+extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, const int64_t *t, int t_uniform,
+                                const uint8_t *drop0, const uint8_t *drop1, const uint8_t *drop2, float drop_p,
+                                uint64_t seed, uint64_t stream_id, float bn_eps, const int32_t *offsets,
+                                const uint8_t *is_cat, int C, int apply_head, float *out, int64_t rows,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    if (!w || !x_t || !out || rows < 1) return DDG_E_ARG;
+    const int D = w->in_dim, E = w->enc_dim, L = w->lat_dim;
+    if (D < 1 || E < 1 || L < 1) return DDG_E_ARG;
+    if (workspace_bytes < ddg_denoiser_workspace_bytes(rows, D, E, L) || !workspace) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t mx = (size_t)(E > L ? E : L);
+    char *p = (char *)workspace;
+    float *z1 = (float *)p; p += align256((size_t)rows * E * 4);
+    float *z2 = (float *)p; p += align256((size_t)rows * L * 4);
+    double *st[3];
+    for (int i = 0; i < 3; ++i) { st[i] = (double *)p; p += align256(2 * mx * 8); }
+    float *sc[3], *sh[3];
+    for (int i = 0; i < 3; ++i) { sc[i] = (float *)p; p += align256(mx * 4); sh[i] = (float *)p; p += align256(mx * 4); }
+    if (hipMemsetAsync(st[0], 0, 3 * align256(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
+    int rc;
+    // layer 1: (x + temb[t]) W1^T + b1
+    rc = ddg_linear(x_t, nullptr, D, w->W1, w->b1, DDG_PRO_ADD_EMB, w->temb, t, t_uniform, nullptr, nullptr, nullptr,
+                    0.f, 0, 0, z1, st[0], rows, D, E, stream);
+    if (rc) return rc;
+    rc = ddg_bn_finalize(st[0], w->g1, w->be1, (double)rows, bn_eps, sc[0], sh[0], E, stream);
+    if (rc) return rc;
+    // layer 2: drop(relu(bn(z1))) W2^T + b2
+    rc = ddg_linear(z1, nullptr, E, w->W2, w->b2, DDG_PRO_BN_RELU, nullptr, nullptr, 0, sc[0], sh[0], drop0, drop_p,
+                    seed, stream_id * 4 + 0, z2, st[1], rows, E, L, stream);
+    if (rc) return rc;
+    rc = ddg_bn_finalize(st[1], w->g2, w->be2, (double)rows, bn_eps, sc[1], sh[1], L, stream);
+    if (rc) return rc;
+    // layer 3 (z3 overwrites z1: z1 is dead once layer 2 has been enqueued, same stream)
+    rc = ddg_linear(z2, nullptr, L, w->W3, w->b3, DDG_PRO_BN_RELU, nullptr, nullptr, 0, sc[1], sh[1], drop1, drop_p,
+                    seed, stream_id * 4 + 1, z1, st[2], rows, L, E, stream);
+    if (rc) return rc;
+    rc = ddg_bn_finalize(st[2], w->g3, w->be3, (double)rows, bn_eps, sc[2], sh[2], E, stream);
+    if (rc) return rc;
+    // layer 4 -> logits
+    rc = ddg_linear(z1, nullptr, E, w->W4, w->b4, DDG_PRO_BN_RELU, nullptr, nullptr, 0, sc[2], sh[2], drop2, drop_p,
+                    seed, stream_id * 4 + 2, out, nullptr, rows, E, D, stream);
+    if (rc) return rc;
+    if (apply_head) {
+        if (!offsets || !is_cat || C < 1) return DDG_E_ARG;
+        rc = ddg_head(out, offsets, is_cat, C, out, rows, D, stream);
+        if (rc) return rc;
+    }
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10 Discriminator_noise_x.forward.  workspace: h1 [rows,lat] | h2 [rows,lat]
+// The final sigmoid is a single-"numeric-field"-per-column head; done by a tiny kernel here.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sigmoid(float *__restrict__ y, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        y[e] = 1.f / (1.f + expf(-y[e]));
+}
+
+extern "C" size_t ddg_disc_workspace_bytes(int64_t rows, int lat_dim) {
+    return 2 * align256((size_t)rows * lat_dim * 4);
+}
+
+extern "C" int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const float *xt, const int64_t *t,
+                            int t_uniform, float *out, int64_t rows, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    if (!w || !xtj1 || !xt || !out || rows < 1) return DDG_E_ARG;
+    const int I = w->in_dim, L = w->lat_dim, O = w->out_dim;
+    if (I < 2 || (I & 1) || L < 1 || O < 1) return DDG_E_ARG;
+    if (!workspace || workspace_bytes < ddg_disc_workspace_bytes(rows, L)) return DDG_E_WORKSPACE;
+    float *h1 = (float *)workspace;
+    float *h2 = (float *)((char *)workspace + align256((size_t)rows * L * 4));
+    int rc;
+    rc = ddg_linear(xtj1, xt, I / 2, w->W1, w->b1, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0,
+                    0, h1, nullptr, rows, I, L, stream);
+    if (rc) return rc;
+    rc = ddg_linear(h1, nullptr, L, w->W2, w->b2, DDG_PRO_EMB_RELU, w->e1, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, h2, nullptr, rows, L, L, stream);
+    if (rc) return rc;
+    rc = ddg_linear(h2, nullptr, L, w->W3, w->b3, DDG_PRO_EMB_RELU, w->e2, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, h1, nullptr, rows, L, L, stream);
+    if (rc) return rc;
+    rc = ddg_linear(h1, nullptr, L, w->W4, w->b4, DDG_PRO_EMB_RELU, w->e3, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, out, nullptr, rows, L, O, stream);
+    if (rc) return rc;
+    const int64_t n = rows * O;
+    int64_t g = ceil_div64(n, 256);
+    if (g > 4096) g = 4096;
+    k_sigmoid<<<(int)g, 256, 0, (hipStream_t)stream>>>(out, n);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

@@ -1,0 +1,44 @@
+"""Host-side mirror of the reference's ``model/Discriminator_model.py`` (time-conditioned
+discriminator), backed by ddg_disc_fwd."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import DiscParams
+
+
+class Discriminator_noise_x(nn.Module):
+    """Parameter container, reference layout (model/Discriminator_model.py:82-102); forward =
+    cat -> 3x[Linear, + step_embedding[t], ReLU] -> Linear -> sigmoid (:105-115) on the GPU."""
+
+    def __init__(self, input_dim, latent_dim, output_dim, n_steps):
+        super().__init__()
+        self.linears = nn.ModuleList([nn.Linear(input_dim, latent_dim), nn.ReLU(), nn.Linear(latent_dim, latent_dim),
+                                      nn.ReLU(), nn.Linear(latent_dim, latent_dim), nn.ReLU(),
+                                      nn.Linear(latent_dim, output_dim)])
+        self.step_embeddings = nn.ModuleList([nn.Embedding(n_steps, latent_dim) for _ in range(3)])
+        self._params = None
+
+    def device_params(self, refresh: bool = False) -> DiscParams:
+        if self._params is None or refresh:
+            self._params = DiscParams(self.state_dict(), self.linears[0].weight.device)
+        return self._params
+
+    def forward(self, xtj1, xt, t):
+        return ops.disc_fwd(self.device_params(refresh=True), xtj1, xt, t if isinstance(t, int) else t.contiguous())
+
+
+def sampler_disc_tail(disc: Discriminator_noise_x, DS, x, x0_hat, eps2: Optional[torch.Tensor] = None,
+                      seed: int = 0):
+    """The t=2 tail of the reference sampler (model/Diffusion.py:442-447): X_2 = q(x,2;eps2);
+    x_1 = posterior mean(x0_hat, X_2) + std*eps2 where the reference's ``std`` already contains eps2
+    (so the noise enters squared, :443-445); D(x_1, X_2, 2).  A reverse step with M=0 and z=eps2^2
+    is exactly that expression."""
+    T = DS.time_steps
+    X_t, e = ops.forward_noise(x, 2, T, eps=eps2, seed=seed, stream_id=300, return_eps=True)
+    xtj1 = ops.reverse_step(X_t, x, torch.zeros_like(x), x0_hat, 2, T, z=e * e, sched_host=DS.host)
+    return disc(xtj1, X_t, 2)

@@ -1,0 +1,273 @@
+"""torch-tensor front end of the C-ABI (include/ddgani.h).
+
+PyTorch is used for device memory, streams and nothing else: every function hands raw device
+pointers of contiguous tensors to libddgani_hip.so on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DiscWeights, GenWeights, check, lib
+
+PRO_NONE, PRO_ADD_EMB, PRO_BN_RELU, PRO_EMB_RELU = 0, 1, 2, 3
+_NAMES8 = ("betas", "alphas", "sqrt_alphas", "one_by_sqrt_alpha_s", "sqrt_beta_s", "alpha_cumulative",
+           "sqrt_alpha_cumulative", "sqrt_one_minus_alpha_cumulative")
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.DdgError("ddgani_amd ops need tensors on the GPU (no CPU fallback)")
+    if not t.is_contiguous():
+        raise _lib.DdgError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.DdgError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class FieldLayout:
+    """Encoded-column layout of a table: column c occupies [offsets[c], offsets[c+1])."""
+
+    def __init__(self, widths: Sequence[int], device=None):
+        self.widths = [int(w) for w in widths]
+        self.offsets = [0]
+        for w in self.widths:
+            self.offsets.append(self.offsets[-1] + w)
+        self.is_cat = [w > 1 for w in self.widths]
+        self.C = len(self.widths)
+        self.D = self.offsets[-1]
+        self._dev = {}
+        self.offsets_host = (C.c_int32 * (self.C + 1))(*self.offsets)
+        if device is not None:
+            self.on(device)
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.tensor(self.offsets, dtype=torch.int32, device=device),
+                              torch.tensor(self.is_cat, dtype=torch.uint8, device=device))
+        return self._dev[key]
+
+
+# --------------------------------------------------------------------------- a3
+def schedule(T: int) -> np.ndarray:
+    """[8,T] fp32: rows in the order of ddg_schedule (Diffusion_setting, model/Diffusion.py:93-108)."""
+    out = np.zeros((8, T), dtype=np.float32)
+    check(lib().ddg_schedule(T, out.ctypes.data_as(C.POINTER(C.c_float))), "ddg_schedule")
+    return out
+
+
+def schedule_dict(T: int):
+    s = schedule(T)
+    return {n: s[i] for i, n in enumerate(_NAMES8)}
+
+
+# --------------------------------------------------------------------------- a5
+def forward_noise(x0: torch.Tensor, t, T: int, eps: Optional[torch.Tensor] = None, seed: int = 0,
+                  stream_id: int = 0, sched_dev: Optional[torch.Tensor] = None, return_eps: bool = False):
+    rows, D = x0.shape
+    x_t = torch.empty_like(x0)
+    eps_out = torch.empty_like(x0) if (return_eps and eps is None) else None
+    if isinstance(t, torch.Tensor):
+        if sched_dev is None:
+            sched_dev = torch.from_numpy(schedule(T)).to(x0.device)
+        tp, tu = _ptr(t, torch.int64), 0
+    else:
+        tp, tu = None, int(t)
+    check(lib().ddg_forward_noise(_ptr(x0, torch.float32), _ptr(eps, torch.float32), tp, tu,
+                                  _ptr(sched_dev, torch.float32), T, seed, stream_id, _ptr(x_t), _ptr(eps_out),
+                                  rows, D, _stream()), "ddg_forward_noise")
+    if return_eps:
+        return x_t, (eps if eps is not None else eps_out)
+    return x_t
+
+
+# --------------------------------------------------------------------------- a7
+def reverse_step(x_t, x, M, pred, t: int, T: int, z=None, seed: int = 0, stream_id: int = 0, out=None,
+                 sched_host: Optional[np.ndarray] = None):
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    sh = schedule(T) if sched_host is None else sched_host
+    check(lib().ddg_reverse_step(_ptr(x_t, torch.float32), _ptr(x, torch.float32), _ptr(M, torch.float32),
+                                 _ptr(pred, torch.float32), _ptr(z, torch.float32),
+                                 sh.ctypes.data_as(C.POINTER(C.c_float)), T, int(t), seed, stream_id, _ptr(out),
+                                 rows, D, _stream()), "ddg_reverse_step")
+    return out
+
+
+# --------------------------------------------------------------------------- a6 head / a9
+def head(y, layout: FieldLayout, out=None):
+    rows, D = y.shape
+    off, cat = layout.on(y.device)
+    if out is None:
+        out = torch.empty_like(y)
+    check(lib().ddg_head(_ptr(y, torch.float32), _ptr(off), _ptr(cat), layout.C, _ptr(out), rows, D, _stream()),
+          "ddg_head")
+    return out
+
+
+def mask_merge(x, M, xhat, layout: FieldLayout, out=None):
+    rows, D = x.shape
+    off, cat = layout.on(x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().ddg_mask_merge(_ptr(x, torch.float32), _ptr(M, torch.float32), _ptr(xhat, torch.float32), _ptr(off),
+                               _ptr(cat), layout.C, _ptr(out), rows, D, _stream()), "ddg_mask_merge")
+    return out
+
+
+# --------------------------------------------------------------------------- dense layer
+def linear(A, W, bias, prologue=PRO_NONE, A2=None, emb=None, t=None, scale=None, shift=None, drop=None,
+           drop_p: float = 0.0, seed: int = 0, stream_id: int = 0, stats=None, out=None):
+    rows = A.shape[0]
+    in1 = A.shape[1]
+    inn = in1 + (A2.shape[1] if A2 is not None else 0)
+    outd = W.shape[0]
+    assert W.shape[1] == inn
+    if out is None:
+        out = torch.empty((rows, outd), dtype=torch.float32, device=A.device)
+    if isinstance(t, torch.Tensor):
+        tp, tu = _ptr(t, torch.int64), 0
+    else:
+        tp, tu = None, int(t or 0)
+    check(lib().ddg_linear(_ptr(A, torch.float32), _ptr(A2, torch.float32), in1, _ptr(W, torch.float32),
+                           _ptr(bias, torch.float32), prologue, _ptr(emb, torch.float32), tp, tu,
+                           _ptr(scale, torch.float32), _ptr(shift, torch.float32), _ptr(drop, torch.uint8),
+                           float(drop_p), seed, stream_id, _ptr(out), _ptr(stats, torch.float64), rows, inn, outd,
+                           _stream()), "ddg_linear")
+    return out
+
+
+def bn_finalize(stats, gamma, beta, total_rows: float, eps: float = 1e-5):
+    width = gamma.shape[0]
+    scale = torch.empty(width, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    check(lib().ddg_bn_finalize(_ptr(stats, torch.float64), _ptr(gamma, torch.float32), _ptr(beta, torch.float32),
+                                float(total_rows), eps, _ptr(scale), _ptr(shift), width, _stream()),
+          "ddg_bn_finalize")
+    return scale, shift
+
+
+# --------------------------------------------------------------------------- a6 / a10 whole nets
+class GenParams:
+    """Device copy of a Generator_x0 state_dict (key layout of model/Diffusion.py:148-178)."""
+
+    def __init__(self, sd, device):
+        g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        self.t = {k: g(k) for k in ("linears.0.weight", "linears.0.bias", "linears.1.weight", "linears.1.bias",
+                                    "linears.4.weight", "linears.4.bias", "linears.5.weight", "linears.5.bias",
+                                    "linears.8.weight", "linears.8.bias", "linears.9.weight", "linears.9.bias",
+                                    "linears.12.weight", "linears.12.bias", "time_embedding.weight")}
+        t = self.t
+        self.in_dim = t["linears.0.weight"].shape[1]
+        self.enc_dim = t["linears.0.weight"].shape[0]
+        self.lat_dim = t["linears.4.weight"].shape[0]
+        self.n_steps = t["time_embedding.weight"].shape[0]
+        self.c = GenWeights(self.in_dim, self.enc_dim, self.lat_dim, self.n_steps,
+                            *[t[k].data_ptr() for k in ("linears.0.weight", "linears.0.bias", "linears.1.weight",
+                                                        "linears.1.bias", "linears.4.weight", "linears.4.bias",
+                                                        "linears.5.weight", "linears.5.bias", "linears.8.weight",
+                                                        "linears.8.bias", "linears.9.weight", "linears.9.bias",
+                                                        "linears.12.weight", "linears.12.bias",
+                                                        "time_embedding.weight")])
+
+
+class DiscParams:
+    """Device copy of a Discriminator_noise_x state_dict (model/Discriminator_model.py:85-102)."""
+
+    def __init__(self, sd, device):
+        g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous()
+        keys = ("linears.0.weight", "linears.0.bias", "linears.2.weight", "linears.2.bias", "linears.4.weight",
+                "linears.4.bias", "linears.6.weight", "linears.6.bias", "step_embeddings.0.weight",
+                "step_embeddings.1.weight", "step_embeddings.2.weight")
+        self.t = {k: g(k) for k in keys}
+        t = self.t
+        self.in_dim = t["linears.0.weight"].shape[1]
+        self.lat_dim = t["linears.0.weight"].shape[0]
+        self.out_dim = t["linears.6.weight"].shape[0]
+        self.n_steps = t["step_embeddings.0.weight"].shape[0]
+        self.c = DiscWeights(self.in_dim, self.lat_dim, self.out_dim, self.n_steps, *[t[k].data_ptr() for k in keys])
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
+    key = (str(device), tag)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def denoiser_fwd(P: GenParams, x_t, t, layout: FieldLayout, drops=None, drop_p: float = 0.2, seed: int = 0,
+                 stream_id: int = 0, bn_eps: float = 1e-5, apply_head: bool = True, out=None):
+    rows = x_t.shape[0]
+    nb = lib().ddg_denoiser_workspace_bytes(rows, P.in_dim, P.enc_dim, P.lat_dim)
+    ws = _workspace(nb, x_t.device, "den")
+    off, cat = layout.on(x_t.device)
+    if out is None:
+        out = torch.empty_like(x_t)
+    if isinstance(t, torch.Tensor):
+        tp, tu = _ptr(t, torch.int64), 0
+    else:
+        tp, tu = None, int(t)
+    d = [None, None, None] if drops is None else [_ptr(m, torch.uint8) for m in drops]
+    check(lib().ddg_denoiser_fwd(C.byref(P.c), _ptr(x_t, torch.float32), tp, tu, d[0], d[1], d[2], float(drop_p),
+                                 seed, stream_id, bn_eps, _ptr(off), _ptr(cat), layout.C, int(apply_head), _ptr(out),
+                                 rows, ws.data_ptr(), ws.numel(), _stream()), "ddg_denoiser_fwd")
+    return out
+
+
+def disc_fwd(P: DiscParams, xtj1, xt, t, out=None):
+    rows = xt.shape[0]
+    nb = lib().ddg_disc_workspace_bytes(rows, P.lat_dim)
+    ws = _workspace(nb, xt.device, "disc")
+    if out is None:
+        out = torch.empty((rows, P.out_dim), dtype=torch.float32, device=xt.device)
+    if isinstance(t, torch.Tensor):
+        tp, tu = _ptr(t, torch.int64), 0
+    else:
+        tp, tu = None, int(t)
+    check(lib().ddg_disc_fwd(C.byref(P.c), _ptr(xtj1, torch.float32), _ptr(xt, torch.float32), tp, tu, _ptr(out), rows,
+                             ws.data_ptr(), ws.numel(), _stream()), "ddg_disc_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------- a1 + a2
+def attn_topk_fill(Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offset: int = 0, debug: bool = False,
+                   out=None):
+    """Row-attention top-k fill (ddg_attn_topk_fill).  Xq0/Xk0: masked encoded rows [N,D] fp32;
+    mq/mk: uint8 [N,C]; W: [C,D].  Returns new_code [Nq,D] (+ tau, nvalid when debug)."""
+    Nq, D = Xq0.shape
+    Nk = Xk0.shape[0]
+    Cc = layout.C
+    nb = lib().ddg_attn_workspace_bytes(Nq, Nk, Cc, D, int(k))
+    if nb == 0:
+        raise _lib.DdgError(f"attention fill: unsupported shape D={D} (max {256})")
+    ws = _workspace(nb, Xq0.device, "attn")
+    if out is None:
+        out = torch.empty_like(Xq0)
+    tau = nval = None
+    if debug:
+        tau = torch.full((Nq, Cc), float("nan"), dtype=torch.float32, device=Xq0.device)
+        nval = torch.full((Nq, Cc), -1, dtype=torch.int32, device=Xq0.device)
+    check(lib().ddg_attn_topk_fill(_ptr(Xq0, torch.float32), _ptr(mq, torch.uint8), q_row_offset,
+                                   _ptr(Xk0, torch.float32), _ptr(mk, torch.uint8), _ptr(W, torch.float32),
+                                   layout.offsets_host, Nq, Nk, Cc, D, int(k), _ptr(out), _ptr(tau), _ptr(nval),
+                                   ws.data_ptr(), ws.numel(), _stream()), "ddg_attn_topk_fill")
+    if debug:
+        return out, tau, nval
+    return out

@@ -1,0 +1,197 @@
+/*
+ * ddgani.h — C-ABI of libddgani_hip.so, the MI355X (gfx950) implementation of DDGANI's
+ * imputation hot path.
+ *
+ * The reference (xianghuang2/DDGANI) has NO native/FFI boundary: its hot path sits behind
+ * plain Python functions that call stock ATen ops.  Each entry point below
+ * therefore cites the reference *Python* function (file:line, relative to the reference
+ * tree) whose ATen op sequence it replaces.  The Python mirror of those functions
+ * (ddgani_amd/model/Diffusion.py, ddgani_amd/utils/util.py) binds them with ctypes.
+ *
+ * Conventions
+ *  - every function returns DDG_OK (0) or a negative DDG_E_* code; nothing throws;
+ *  - all data pointers are DEVICE pointers owned by the caller unless marked "host";
+ *  - nothing allocates or frees: scratch memory is a caller-provided workspace whose size
+ *    the matching ddg_*_workspace_bytes() function returns;
+ *  - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream); no entry point synchronises;
+ *  - matrices are row-major contiguous fp32 unless stated otherwise;
+ *  - "field layout": a table column c occupies encoded columns [offsets[c], offsets[c+1])
+ *    (width 1 = numeric, width > 1 = one-hot categorical); offsets is int32[C+1] on the
+ *    DEVICE, D = offsets[C];  is_cat is uint8[C] on the DEVICE.
+ */
+#ifndef DDGANI_H
+#define DDGANI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDG_OK 0
+#define DDG_E_ARG (-1)        /* bad argument (null pointer, negative size, ...)            */
+#define DDG_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for               */
+#define DDG_E_WORKSPACE (-3)  /* workspace too small                                        */
+#define DDG_E_LAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch             */
+
+#define DDG_MAX_D 256         /* widest encoded table the attention kernels are built for   */
+#define DDG_MAX_TOPK_REG 32   /* absolute k up to this uses the in-register selection       */
+
+/* library / error helpers */
+int ddg_version(void);
+const char *ddg_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * a3  Diffusion_setting.initialize          model/Diffusion.py:86-108
+ * Host-side: fills out8[8*T] (host memory, fp32) with betas (beta[0]=0), alphas, sqrt_alphas,
+ * 1/sqrt_alphas, sqrt_betas, alpha_cumulative, sqrt_alpha_cumulative,
+ * sqrt_one_minus_alpha_cumulative, in that order, each of length T.
+ * ------------------------------------------------------------------------------------- */
+int ddg_schedule(int T, float *out8_host);
+
+/* ---------------------------------------------------------------------------------------
+ * a5  forward_diffusion / get_xt            model/Diffusion.py:391-403
+ *   x_t = sqrt(abar_t) * x0 + sqrt(1-abar_t) * eps
+ * eps: explicit noise [rows,D] or NULL -> generated on chip (Philox4x32-10 + Box-Muller,
+ * keyed by seed/stream_id) and, when eps_out != NULL, also written there.
+ * t: int64[rows] per-row timesteps (1..T) or NULL -> every row uses t_uniform.
+ * sched: DEVICE copy of ddg_schedule's out8 (8*T floats).
+ * ------------------------------------------------------------------------------------- */
+int ddg_forward_noise(const float *x0, const float *eps, const int64_t *t, int t_uniform,
+                      const float *sched, int T, uint64_t seed, uint64_t stream_id,
+                      float *x_t, float *eps_out, int64_t rows, int D, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a7  G_D_onestep after the generator call  model/Diffusion.py:415-424   (uniform t)
+ *   g = (sqrt(abar_{t-1}) b_t pred + sqrt(a_t)(1-abar_{t-1}) x_t)/(1-abar_t)
+ *       + (1-abar_{t-1}) b_t z/(1-abar_t)
+ *   o = sqrt(abar_{t-1}) x + sqrt(1-abar_{t-1}) z ;   out = M o + (1-M) g
+ * z: explicit noise or NULL -> on-chip Philox.  sched_host: HOST copy of ddg_schedule's out8.
+ * In-place (out == x_t) is allowed.  Requires 3 <= t <= T.
+ * ------------------------------------------------------------------------------------- */
+int ddg_reverse_step(const float *x_t, const float *x, const float *M, const float *pred,
+                     const float *z, const float *sched_host, int T, int t,
+                     uint64_t seed, uint64_t stream_id, float *out, int64_t rows, int D,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a6 (head)  per-field sigmoid / softmax   model/Diffusion.py:188-201
+ * a9  mask-merge + categorical re-softmax  model/Diffusion.py:598, :606-615
+ *   ddg_head:        out = head(y)
+ *   ddg_mask_merge:  code = M*x + (1-M)*xhat, then softmax over every categorical block
+ * In-place allowed.
+ * ------------------------------------------------------------------------------------- */
+int ddg_head(const float *y, const int32_t *offsets, const uint8_t *is_cat, int C,
+             float *out, int64_t rows, int D, void *stream);
+int ddg_mask_merge(const float *x, const float *M, const float *xhat, const int32_t *offsets,
+                   const uint8_t *is_cat, int C, float *code, int64_t rows, int D, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense layer used by a6 (Generator_x0.forward, model/Diffusion.py:179-187) and a10
+ * (Discriminator_noise_x.forward, model/Discriminator_model.py:105-115):
+ *
+ *   Y[rows,out] = f(A)[rows,in] * W[out,in]^T + bias[out]
+ *
+ * f is the fused A-operand prologue:
+ *   DDG_PRO_NONE     f(a) = a
+ *   DDG_PRO_ADD_EMB  f(a)[r,k] = a[r,k] + emb[t_r, k]          (time_embedding add, :180)
+ *   DDG_PRO_BN_RELU  f(a)[r,k] = relu(a[r,k]*scale[k]+shift[k]) * drop[r,k]
+ *                    (BatchNorm apply + ReLU + Dropout of the previous layer, :184-186;
+ *                     scale/shift come from ddg_bn_finalize)
+ *   DDG_PRO_EMB_RELU f(a)[r,k] = relu(a[r,k] + emb[t_r,k])     (Discriminator_model.py:110-112)
+ * A may be the concatenation [A | A2] along columns (torch.cat, Discriminator_model.py:106):
+ * columns [0,in1) come from A (row stride in1), [in1,in) from A2 (row stride in-in1);
+ * A2 == NULL -> in1 must equal in.
+ * drop: uint8[rows,in] keep-mask (1 = keep, scaled by 1/(1-p)) or NULL; when NULL and
+ * drop_p > 0 the mask is generated on chip (Philox, seed/stream_id); drop_p == 0 -> none.
+ * t: int64[rows] or NULL (t_uniform).  emb: [n_steps,in].
+ * stats (optional, may be NULL): double[2*out]; the kernel ADDS column sums of Y and Y^2
+ * (fp64) into it (zero it first; multi-GPU callers all-reduce it before ddg_bn_finalize).
+ * ------------------------------------------------------------------------------------- */
+#define DDG_PRO_NONE 0
+#define DDG_PRO_ADD_EMB 1
+#define DDG_PRO_BN_RELU 2
+#define DDG_PRO_EMB_RELU 3
+
+int ddg_linear(const float *A, const float *A2, int in1, const float *W, const float *bias,
+               int prologue, const float *emb, const int64_t *t, int t_uniform,
+               const float *scale, const float *shift, const uint8_t *drop, float drop_p,
+               uint64_t seed, uint64_t stream_id, float *Y, double *stats,
+               int64_t rows, int in, int out, void *stream);
+
+/* BatchNorm1d (train mode, biased variance, eps)   model/Diffusion.py:151,156,161
+ * scale[k] = gamma[k]/sqrt(var[k]+eps), shift[k] = beta[k]-mean[k]*scale[k] from the fp64
+ * column sums produced by ddg_linear over `total_rows` rows (the GLOBAL row count). */
+int ddg_bn_finalize(const double *stats, const float *gamma, const float *beta, double total_rows,
+                    float eps, float *scale, float *shift, int width, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a6  Generator_x0.forward (train mode)     model/Diffusion.py:145-201
+ * One call = time-embedding add, 3 x [Linear, BatchNorm(batch stats), ReLU, Dropout(p)],
+ * Linear, per-field head.  Single-GPU convenience over ddg_linear/ddg_bn_finalize/ddg_head
+ * (row-sharded callers drive the layers themselves and all-reduce the BN sums in between).
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddg_gen_weights {
+    int32_t in_dim, enc_dim, lat_dim, n_steps;  /* D, 2D, D, T+1 (BaseLine/DiffGANI.py:54) */
+    const float *W1, *b1, *g1, *be1;            /* linears.0 [enc,in], linears.1 BN [enc]   */
+    const float *W2, *b2, *g2, *be2;            /* linears.4 [lat,enc], linears.5 BN [lat]  */
+    const float *W3, *b3, *g3, *be3;            /* linears.8 [enc,lat], linears.9 BN [enc]  */
+    const float *W4, *b4;                       /* linears.12 [in,enc]                      */
+    const float *temb;                          /* time_embedding.weight [n_steps,in]       */
+} ddg_gen_weights;
+
+size_t ddg_denoiser_workspace_bytes(int64_t rows, int in_dim, int enc_dim, int lat_dim);
+/* drop0..2: explicit keep-masks uint8 [rows,enc],[rows,lat],[rows,enc] or NULL (on-chip RNG
+ * when drop_p > 0).  apply_head == 0 leaves the pre-head logits in `out`. */
+int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, const int64_t *t, int t_uniform,
+                     const uint8_t *drop0, const uint8_t *drop1, const uint8_t *drop2, float drop_p,
+                     uint64_t seed, uint64_t stream_id, float bn_eps,
+                     const int32_t *offsets, const uint8_t *is_cat, int C, int apply_head,
+                     float *out, int64_t rows, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a10  Discriminator_noise_x.forward        model/Discriminator_model.py:82-115
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddg_disc_weights {
+    int32_t in_dim, lat_dim, out_dim, n_steps;  /* 2D, D/2, C, T+1 (BaseLine/DiffGANI.py:53) */
+    const float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4;   /* linears.0,2,4,6               */
+    const float *e1, *e2, *e3;                  /* step_embeddings.{0,1,2}.weight [n_steps,lat] */
+} ddg_disc_weights;
+
+size_t ddg_disc_workspace_bytes(int64_t rows, int lat_dim);
+int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const float *xt, const int64_t *t,
+                 int t_uniform, float *out, int64_t rows, void *workspace, size_t workspace_bytes,
+                 void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a1 + a2  init_attn_2 core: row-attention top-k fill   utils/util.py:439-496
+ *
+ * For every local query row j and table column c with mq[j,c]==0:
+ *   logits  s_i = sum_d W[c,d] * Xq0[j,d] * Xk0[i,d]     over keys i with mk[i,c]==1, i != j
+ *   tau     = k-th largest logit (all valid keys kept when fewer than k exist; ties kept)
+ *   fill    = sum_{s_i >= tau} softmax_i * Xk0[i, blk(c)]
+ *   out_code[j, blk(c)] = fill          ;  cells with mq[j,c]==1 keep Xq0[j, blk(c)]
+ * which is the closed form of softmax(dim=0) -> top-k probability threshold -> renormalise
+ * -> P^T X0 -> mask-merge.  Xq0/Xk0 are the encoded rows already multiplied
+ * by their expanded masks (X0 = X*M, utils/util.py:439).  Queries are the caller's row shard
+ * (q_row_offset = global index of its first row); keys are all rows (after the all-gather
+ * in the multi-GPU case).  On one GPU pass the same pointers for queries and keys.
+ * mq/mk: uint8 0/1 [rows,C].  W: [C,D].  offsets: int32[C+1] on the HOST here.
+ * k >= 1.  k <= DDG_MAX_TOPK_REG selects in registers (one similarity pass + one fill pass);
+ * larger k uses an exact 5-level radix select on the logits (5 similarity passes + fill).
+ * Optional debug outputs (NULL to skip): out_tau [Nq,C] (NaN where mq==1, -inf when all
+ * valid keys are kept), out_nvalid int32 [Nq,C].
+ * ------------------------------------------------------------------------------------- */
+size_t ddg_attn_workspace_bytes(int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k);
+int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset,
+                       const float *Xk0, const uint8_t *mk, const float *W,
+                       const int32_t *offsets_host, int64_t n_query_rows, int64_t n_key_rows,
+                       int C, int D, int64_t k, float *out_code, float *out_tau, int32_t *out_nvalid,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDGANI_H */
