@@ -454,13 +454,16 @@ extern "C" size_t ddg_attn_workspace_bytes(int64_t Nq, int64_t Nk, int C, int D,
 template <int KS4, int MODE, int KCAP>
 static int launch_attn(const AttnArgs &a, int64_t qb_max, size_t extra_bytes, hipStream_t s) {
     const size_t lds = (size_t)2 * TK * (KS4 * 8 + 4) * 4 + extra_bytes;
-    if (lds > 160 * 1024) return DDG_E_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_attn<KS4, MODE, KCAP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
+    if (lds > 160 * 1024 - 64) return DDG_E_UNSUPPORTED;
+    static size_t attr_lds = 48 * 1024;   // dynamic LDS above the default limit must be opted into
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_attn<KS4, MODE, KCAP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            fprintf(stderr, "ddgani: hipFuncSetAttribute(%zu): %s\n", lds, hipGetErrorString(e));
             return DDG_E_LAUNCH;
-        attr_set = true;
+        }
+        attr_lds = lds;
     }
     k_attn<KS4, MODE, KCAP><<<(unsigned)qb_max, 256, lds, s>>>(a);
     DDG_CHECK_LAUNCH();

@@ -4,9 +4,14 @@
 #include <stdint.h>
 #include "../../include/ddgani.h"
 
-#define DDG_CHECK_LAUNCH()                                    \
-    do {                                                      \
-        if (hipGetLastError() != hipSuccess) return DDG_E_LAUNCH; \
+#include <stdio.h>
+#define DDG_CHECK_LAUNCH()                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = hipGetLastError();                                                  \
+        if (e__ != hipSuccess) {                                                             \
+            fprintf(stderr, "ddgani: %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); \
+            return DDG_E_LAUNCH;                                                             \
+        }                                                                                    \
     } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -101,7 +101,7 @@ __global__ void k_forward_noise_rows(const float *__restrict__ x0, const float *
         float ev;
         if (eps) ev = eps[e];
         else ev = philox_normal4(seed, stream_id, (uint64_t)(e >> 2))[e & 3];
-        xt[e] = ca * x0[e] + cb * ev;
+        xt[e] = __fadd_rn(__fmul_rn(ca, x0[e]), __fmul_rn(cb, ev));
         if (eps_out) eps_out[e] = ev;
     }
 }
@@ -145,11 +145,11 @@ extern "C" int ddg_forward_noise(const float *x0, const float *eps, const int64_
 struct RevCoef { float c1, c2, c3, den, sacm1, s1mm1; };
 
 __device__ __forceinline__ float rev_one(float xt, float x, float M, float p, float z, const RevCoef &k) {
-    const float gm = (k.c1 * p + k.c2 * xt) / k.den;
-    const float gs = (k.c3 * z) / k.den;
-    const float g = gm + gs;
-    const float o = k.sacm1 * x + k.s1mm1 * z;
-    return M * o + (1.f - M) * g;
+    const float gm = __fdiv_rn(__fadd_rn(__fmul_rn(k.c1, p), __fmul_rn(k.c2, xt)), k.den);
+    const float gs = __fdiv_rn(__fmul_rn(k.c3, z), k.den);
+    const float g = __fadd_rn(gm, gs);
+    const float o = __fadd_rn(__fmul_rn(k.sacm1, x), __fmul_rn(k.s1mm1, z));
+    return __fadd_rn(__fmul_rn(M, o), __fmul_rn(__fsub_rn(1.f, M), g));
 }
 
 __global__ void k_reverse_step(const float *__restrict__ xt, const float *__restrict__ x, const float *__restrict__ M,

@@ -34,7 +34,7 @@ def test_forward_noise_and_reverse_step(dev, name, T):
     x_T = ops.forward_noise(x, T, T, eps=torch.tensor(z["eps_T"]).to(dev))
     assert np.array_equal(x_T.cpu().numpy(), z["x_T"])
     out = ops.reverse_step(x_T, x, M, torch.tensor(z["pred_T"]).to(dev), T, T, z=torch.tensor(z["z0"]).to(dev))
-    np.testing.assert_allclose(out.cpu().numpy(), z["x_Tm1"], rtol=0, atol=2.5e-7)
+    assert np.array_equal(out.cpu().numpy(), z["x_Tm1"])
 
 
 def test_forward_noise_per_row_t(dev):
@@ -44,7 +44,10 @@ def test_forward_noise_per_row_t(dev):
     x0 = torch.tensor(z["x0"]).to(dev)
     t = torch.tensor(z["t"]).to(dev)
     xt = ops.forward_noise(x0, t, T, eps=torch.tensor(z["eps"]).to(dev))
-    ref = orc.forward_noise(orc.schedule(T), torch.tensor(z["x0"]), torch.tensor(z["t"]), torch.tensor(z["eps"]))
+    # schedule from the C entry point (pinned to the golden schedule in test_abi): torch's vectorised sqrt is
+    # not correctly rounded on every host CPU, so orc.schedule() may differ by 1 ulp between machines
+    S = {k: torch.tensor(v) for k, v in ops.schedule_dict(T).items()}
+    ref = orc.forward_noise(S, torch.tensor(z["x0"]), torch.tensor(z["t"]), torch.tensor(z["eps"]))
     assert np.array_equal(xt.cpu().numpy(), ref.numpy())
 
 
