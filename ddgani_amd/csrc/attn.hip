@@ -412,6 +412,7 @@ struct AttnWs {
     float *tau, *smax;
     uint32_t *prefix;
     int32_t *rank;
+    int32_t *flags;            // [0] = 1 when queries alias keys (set by prepare)
     size_t total;
     int64_t qb_max;
     int nchunk_k, nchunk_q;
@@ -425,13 +426,15 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
     w.nchunk_q = (int)ceil_div64(Nq, 256);
     w.qb_max = (Nq * C) / QPB + C;
     w.Xkp = (float *)take((size_t)Nk * DP * 4);
-    w.Xqp = same ? w.Xkp : (float *)take((size_t)Nq * DP * 4);
+    w.Xqp = (float *)take((size_t)Nq * DP * 4);
+    if (same) w.Xqp = w.Xkp;
     w.Wp = (float *)take((size_t)C * DP * 4);
     w.klist = (int32_t *)take((size_t)C * Nk * 4);
     w.nk = (int32_t *)take((size_t)C * 4);
     w.obs_q = (int32_t *)take((size_t)C * 4);
     w.cnt_k = (int32_t *)take((size_t)C * w.nchunk_k * 4);
-    w.cnt_q = same ? w.cnt_k : (int32_t *)take((size_t)C * w.nchunk_q * 4);
+    w.cnt_q = (int32_t *)take((size_t)C * w.nchunk_q * 4);
+    if (same) w.cnt_q = w.cnt_k;
     w.qlist = (int32_t *)take((size_t)w.qb_max * QPB * 4);
     w.qb_start = (int32_t *)take((size_t)(C + 1) * 4);
     w.offsets = (int32_t *)take((size_t)(C + 1) * 4);
@@ -439,6 +442,7 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
     w.smax = (float *)take((size_t)w.qb_max * QPB * 4);
     w.prefix = (uint32_t *)take((size_t)w.qb_max * QPB * 4);
     w.rank = (int32_t *)take((size_t)w.qb_max * QPB * 4);
+    w.flags = (int32_t *)take(256);
     w.total = o;
 }
 
@@ -446,8 +450,7 @@ extern "C" size_t ddg_attn_workspace_bytes(int64_t Nq, int64_t Nk, int C, int D,
     (void)k;
     if (ks4_for(D) == 0 || Nq < 0 || Nk < 0 || C < 1) return 0;
     AttnWs w;
-    // worst case: queries and keys are distinct arrays
-    attn_carve(w, nullptr, Nq, Nk, C, D, false);
+    attn_carve(w, nullptr, Nq, Nk, C, D, false);   // the layout does not depend on aliasing
     return w.total;
 }
 
@@ -471,56 +474,60 @@ static int launch_attn(const AttnArgs &a, int64_t qb_max, size_t extra_bytes, hi
 }
 
 template <int KS4>
-static int run_passes(AttnArgs &a, int64_t qb_max, int dcmax, hipStream_t s) {
+static int run_select(AttnArgs &a, int64_t qb_max, hipStream_t s) {
     int rc;
-    if (a.k <= 16) {
-        rc = launch_attn<KS4, MODE_TOPK, 16>(a, qb_max, 0, s);
+    if (a.k <= 16) return launch_attn<KS4, MODE_TOPK, 16>(a, qb_max, 0, s);
+    if (a.k <= 32) return launch_attn<KS4, MODE_TOPK, 32>(a, qb_max, 0, s);
+    for (int L = 0; L < 5; ++L) {
+        a.level = L;
+        rc = launch_attn<KS4, MODE_HIST, 1>(a, qb_max, (size_t)QPB * HSTRIDE * 4, s);
         if (rc) return rc;
-    } else if (a.k <= 32) {
-        rc = launch_attn<KS4, MODE_TOPK, 32>(a, qb_max, 0, s);
-        if (rc) return rc;
-    } else {
-        for (int L = 0; L < 5; ++L) {
-            a.level = L;
-            rc = launch_attn<KS4, MODE_HIST, 1>(a, qb_max, (size_t)QPB * HSTRIDE * 4, s);
-            if (rc) return rc;
-        }
     }
+    return DDG_OK;
+}
+
+template <int KS4>
+static int run_fill(AttnArgs &a, int64_t qb_max, int dcmax, hipStream_t s) {
     a.dcs = dcmax | 1;
     return launch_attn<KS4, MODE_FILL, 1>(a, qb_max, (size_t)256 * a.dcs * 4, s);
 }
 
-extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
-                                  const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
-                                  int64_t Nk, int C, int D, int64_t k, float *out_code, float *out_tau,
-                                  int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!Xq0 || !mq || !Xk0 || !mk || !W || !offsets_host || !out_code) return DDG_E_ARG;
-    if (Nq < 0 || Nk < 1 || C < 1 || D < 1 || k < 1 || q_row_offset < 0 || q_row_offset + Nq > Nk) return DDG_E_ARG;
+static int attn_check_dims(int64_t Nq, int64_t Nk, int C, int D) {
+    if (Nq < 0 || Nk < 1 || C < 1 || D < 1) return DDG_E_ARG;
+    if (ks4_for(D) == 0 || Nk >= (int64_t)1 << 31 || (Nq * C) / QPB + C >= (int64_t)1 << 31) return DDG_E_UNSUPPORTED;
+    return DDG_OK;
+}
+
+static void attn_args(AttnArgs &a, const AttnWs &w, int64_t Nk, int C, int D, int k) {
+    a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.klist = w.klist; a.nk = w.nk; a.qlist = w.qlist;
+    a.qb_start = w.qb_start; a.offsets = w.offsets; a.tau = w.tau; a.smax = w.smax; a.prefix = w.prefix;
+    a.rank = w.rank; a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
+    a.D = D; a.DP = ks4_for(D) * 8; a.k = k; a.level = 0; a.dcs = 1;
+}
+
+// phase 1: padded operands + per-column key / query index lists
+extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
+                                const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
+                                int64_t Nk, int C, int D, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!Xq0 || !mq || !Xk0 || !mk || !W || !offsets_host) return DDG_E_ARG;
+    int rc = attn_check_dims(Nq, Nk, C, D);
+    if (rc) return rc;
+    if (q_row_offset < 0 || q_row_offset + Nq > Nk) return DDG_E_ARG;
     if (offsets_host[0] != 0 || offsets_host[C] != D) return DDG_E_ARG;
-    int dcmax = 1;
-    for (int c = 0; c < C; ++c) {
-        const int d = offsets_host[c + 1] - offsets_host[c];
-        if (d < 1) return DDG_E_ARG;
-        if (d > dcmax) dcmax = d;
-    }
-    const int KS4 = ks4_for(D);
-    if (KS4 == 0 || Nk >= (int64_t)1 << 31 || Nq * (int64_t)C >= ((int64_t)1 << 31) * 64) return DDG_E_UNSUPPORTED;
+    for (int c = 0; c < C; ++c)
+        if (offsets_host[c + 1] - offsets_host[c] < 1) return DDG_E_ARG;
     if (Nq == 0) return DDG_OK;
     const bool same = (Xq0 == Xk0 && mq == mk && Nq == Nk);
     AttnWs w;
     attn_carve(w, (char *)workspace, Nq, Nk, C, D, same);
     if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
-    if (w.qb_max >= (int64_t)1 << 31) return DDG_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int DP = KS4 * 8;
-    const int kk = (int)(k > Nk ? Nk : k);
+    const int DP = ks4_for(D) * 8;
 
     if (hipMemcpyAsync(w.offsets, offsets_host, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess)
         return DDG_E_LAUNCH;
     if (hipMemsetAsync(w.qlist, 0xFF, (size_t)w.qb_max * QPB * 4, s) != hipSuccess) return DDG_E_LAUNCH;
-    if (out_code != Xq0 &&
-        hipMemcpyAsync(out_code, Xq0, (size_t)Nq * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return DDG_E_LAUNCH;
+    if (hipMemsetAsync(w.flags, same ? 1 : 0, 4, s) != hipSuccess) return DDG_E_LAUNCH;
 
     auto egrid = [](int64_t n) { int64_t g = ceil_div64(n, 256); return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
     k_pad_rows<<<egrid(Nk * DP), 256, 0, s>>>(Xk0, w.Xkp, Nk, D, DP);
@@ -540,17 +547,75 @@ extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q
         k_fill_lists<false, true><<<w.nchunk_q, 256, 0, s>>>(mq, Nq, C, w.nchunk_q, w.cnt_q, w.klist, Nk, w.qb_start, w.qlist);
     }
     DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
 
+// phase 2: k-th largest logit (tau) and the largest logit per (query row, column) pair
+extern "C" int ddg_attn_select(int64_t Nq, int64_t Nk, int C, int D, int64_t k, int queries_alias_keys,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = attn_check_dims(Nq, Nk, C, D);
+    if (rc) return rc;
+    if (k < 1) return DDG_E_ARG;
+    if (Nq == 0) return DDG_OK;
+    AttnWs w;
+    attn_carve(w, (char *)workspace, Nq, Nk, C, D, queries_alias_keys != 0);
+    if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
     AttnArgs a;
-    a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.klist = w.klist; a.nk = w.nk; a.qlist = w.qlist;
-    a.qb_start = w.qb_start; a.offsets = w.offsets; a.tau = w.tau; a.smax = w.smax; a.prefix = w.prefix;
-    a.rank = w.rank; a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid; a.Nk = Nk; a.C = C;
-    a.D = D; a.DP = DP; a.k = kk; a.level = 0; a.dcs = 1;
-    switch (KS4) {
-        case 8: return run_passes<8>(a, w.qb_max, dcmax, s);
-        case 16: return run_passes<16>(a, w.qb_max, dcmax, s);
-        case 24: return run_passes<24>(a, w.qb_max, dcmax, s);
-        case 32: return run_passes<32>(a, w.qb_max, dcmax, s);
+    attn_args(a, w, Nk, C, D, (int)(k > Nk ? Nk : k));
+    hipStream_t s = (hipStream_t)stream;
+    switch (ks4_for(D)) {
+        case 8: return run_select<8>(a, w.qb_max, s);
+        case 16: return run_select<16>(a, w.qb_max, s);
+        case 24: return run_select<24>(a, w.qb_max, s);
+        case 32: return run_select<32>(a, w.qb_max, s);
     }
     return DDG_E_UNSUPPORTED;
+}
+
+// phase 3: softmax-weighted accumulation over {s >= tau} and mask-merge into out_code
+extern "C" int ddg_attn_fill(const float *Xq0, const int32_t *offsets_host, int64_t Nq, int64_t Nk, int C, int D,
+                             int64_t k, int queries_alias_keys, float *out_code, float *out_tau,
+                             int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!Xq0 || !offsets_host || !out_code) return DDG_E_ARG;
+    int rc = attn_check_dims(Nq, Nk, C, D);
+    if (rc) return rc;
+    if (Nq == 0) return DDG_OK;
+    int dcmax = 1;
+    for (int c = 0; c < C; ++c) {
+        const int d = offsets_host[c + 1] - offsets_host[c];
+        if (d < 1) return DDG_E_ARG;
+        if (d > dcmax) dcmax = d;
+    }
+    AttnWs w;
+    attn_carve(w, (char *)workspace, Nq, Nk, C, D, queries_alias_keys != 0);
+    if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_code != Xq0 &&
+        hipMemcpyAsync(out_code, Xq0, (size_t)Nq * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return DDG_E_LAUNCH;
+    AttnArgs a;
+    attn_args(a, w, Nk, C, D, (int)(k > Nk ? Nk : k));
+    a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
+    switch (ks4_for(D)) {
+        case 8: return run_fill<8>(a, w.qb_max, dcmax, s);
+        case 16: return run_fill<16>(a, w.qb_max, dcmax, s);
+        case 24: return run_fill<24>(a, w.qb_max, dcmax, s);
+        case 32: return run_fill<32>(a, w.qb_max, dcmax, s);
+    }
+    return DDG_E_UNSUPPORTED;
+}
+
+extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
+                                  const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
+                                  int64_t Nk, int C, int D, int64_t k, float *out_code, float *out_tau,
+                                  int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!out_code || k < 1) return DDG_E_ARG;
+    int rc = ddg_attn_prepare(Xq0, mq, q_row_offset, Xk0, mk, W, offsets_host, Nq, Nk, C, D, workspace,
+                              workspace_bytes, stream);
+    if (rc) return rc;
+    const int same = (Xq0 == Xk0 && mq == mk && Nq == Nk) ? 1 : 0;
+    rc = ddg_attn_select(Nq, Nk, C, D, k, same, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return ddg_attn_fill(Xq0, offsets_host, Nq, Nk, C, D, k, same, out_code, out_tau, out_nvalid, workspace,
+                         workspace_bytes, stream);
 }

@@ -1,0 +1,102 @@
+"""Row-sharded (one process per GPU) versions of the hot path.
+
+Each rank owns a contiguous shard of the table's rows.
+ * attention fill: queries = the local shard; the masked key rows and their masks are all-gathered
+   once (RCCL all-gather over xGMI) so every rank scans all keys; outputs are disjoint.
+ * sampler: rows are independent except for train-mode BatchNorm, whose per-layer column sums
+   (2*width fp64) are all-reduced before ddg_bn_finalize: 3 tiny all-reduces per generator call.
+``backend`` is the op module (ddgani_amd.ops on the GPU; the CPU tests inject the oracle-backed
+stand-in from tests/ to exercise the collective logic with gloo).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+
+    def all_gather_rows(self, t: torch.Tensor, counts) -> torch.Tensor:
+        """concatenate the ranks' row shards (shard sizes ``counts``) along dim 0"""
+        if not self.on:
+            return t
+        if len(set(counts)) == 1:
+            out = torch.empty((sum(counts),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            return out
+        parts = [torch.empty((c,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for c in counts]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts, 0)
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.on:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def shard_bounds(N: int, world: int):
+    per = (N + world - 1) // world
+    return [(min(r * per, N), min((r + 1) * per, N)) for r in range(world)]
+
+
+def sharded_attn_fill(comm: Comm, backend, X0_local, m_local, W, layout, k: int, N_total: int, out=None):
+    """top-k attention fill of the local query rows against ALL rows (keys all-gathered)."""
+    bounds = shard_bounds(N_total, comm.world)
+    counts = [b - a for a, b in bounds]
+    lo = bounds[comm.rank][0]
+    if comm.on:
+        Xk = comm.all_gather_rows(X0_local, counts)
+        mk = comm.all_gather_rows(m_local, counts)
+        return backend.attn_topk_fill(X0_local, m_local, Xk, mk, W, layout, k, q_row_offset=lo, out=out)
+    return backend.attn_topk_fill(X0_local, m_local, X0_local, m_local, W, layout, k, out=out)
+
+
+def sharded_denoiser_fwd(comm: Comm, backend, P, x_t, t, layout, N_total: int, drops=None, drop_p: float = 0.2,
+                         seed: int = 0, stream_id: int = 0, row_offset: int = 0, bn_eps: float = 1e-5, out=None):
+    """Generator_x0.forward over a row shard with global (sync) BatchNorm statistics."""
+    w = P.t
+    dev = x_t.device
+    d = [None, None, None] if drops is None else drops
+    h = x_t
+    pro = backend.PRO_ADD_EMB
+    kw = dict(emb=w["time_embedding.weight"], t=t)
+    for l, (li, bi) in enumerate(((0, 1), (4, 5), (8, 9))):
+        Wl, bl = w[f"linears.{li}.weight"], w[f"linears.{li}.bias"]
+        stats = torch.zeros(2 * Wl.shape[0], dtype=torch.float64, device=dev)
+        z = backend.linear(h, Wl, bl, prologue=pro, stats=stats, **kw)
+        comm.all_reduce_sum(stats)
+        scale, shift = backend.bn_finalize(stats, w[f"linears.{bi}.weight"], w[f"linears.{bi}.bias"], float(N_total),
+                                           bn_eps)
+        h = z
+        pro = backend.PRO_BN_RELU
+        # on-chip dropout is keyed by the element index; offset the stream per rank so shards differ
+        kw = dict(scale=scale, shift=shift, drop=d[l], drop_p=drop_p, seed=seed,
+                  stream_id=(stream_id * 4 + l) * 1024 + comm.rank)
+    y = backend.linear(h, w["linears.12.weight"], w["linears.12.bias"], prologue=pro, out=out, **kw)
+    return backend.head(y, layout, out=y)
+
+
+def sharded_reverse_sample(comm: Comm, backend, P, T: int, x, M, layout, N_total: int, randomness=None, seed: int = 0,
+                           drop_p: float = 0.2):
+    """T-step reverse diffusion over a row shard (model/Diffusion.py:426-450), sync-BN across ranks."""
+    r = randomness
+    sid = 1000 * (comm.rank + 1)
+    x_t = backend.forward_noise(x, T, T, eps=None if r is None else r.eps_T, seed=seed, stream_id=sid + 1)
+    pred = None
+    i = 0
+    for ts in range(T, 1, -1):
+        pred = sharded_denoiser_fwd(comm, backend, P, x_t, ts, layout, N_total,
+                                    drops=None if r is None else r.drops[i], drop_p=drop_p, seed=seed,
+                                    stream_id=100 + ts)
+        if ts > 2:
+            x_t = backend.reverse_step(x_t, x, M, pred, ts, T, z=None if r is None else r.zs[i], seed=seed,
+                                       stream_id=sid + 200 + ts, out=x_t)
+        i += 1
+    return pred

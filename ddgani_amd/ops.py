@@ -271,3 +271,37 @@ def attn_topk_fill(Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offse
     if debug:
         return out, tau, nval
     return out
+
+
+class AttnPlan:
+    """The three phases of the attention fill on one workspace (ddg_attn_prepare / _select / _fill)."""
+
+    def __init__(self, Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offset: int = 0):
+        self.Xq0, self.mq, self.Xk0, self.mk, self.W, self.layout, self.k = Xq0, mq, Xk0, mk, W, layout, int(k)
+        self.q_row_offset = q_row_offset
+        self.Nq, self.D = Xq0.shape
+        self.Nk = Xk0.shape[0]
+        self.alias = int(Xq0.data_ptr() == Xk0.data_ptr() and mq.data_ptr() == mk.data_ptr() and self.Nq == self.Nk)
+        nb = lib().ddg_attn_workspace_bytes(self.Nq, self.Nk, layout.C, self.D, self.k)
+        if nb == 0:
+            raise _lib.DdgError(f"attention fill: unsupported shape D={self.D}")
+        self.ws = _workspace(nb, Xq0.device, "attn")
+
+    def prepare(self):
+        check(lib().ddg_attn_prepare(_ptr(self.Xq0, torch.float32), _ptr(self.mq, torch.uint8), self.q_row_offset,
+                                     _ptr(self.Xk0, torch.float32), _ptr(self.mk, torch.uint8),
+                                     _ptr(self.W, torch.float32), self.layout.offsets_host, self.Nq, self.Nk,
+                                     self.layout.C, self.D, self.ws.data_ptr(), self.ws.numel(), _stream()),
+              "ddg_attn_prepare")
+
+    def select(self):
+        check(lib().ddg_attn_select(self.Nq, self.Nk, self.layout.C, self.D, self.k, self.alias, self.ws.data_ptr(),
+                                    self.ws.numel(), _stream()), "ddg_attn_select")
+
+    def fill(self, out=None):
+        if out is None:
+            out = torch.empty_like(self.Xq0)
+        check(lib().ddg_attn_fill(_ptr(self.Xq0, torch.float32), self.layout.offsets_host, self.Nq, self.Nk,
+                                  self.layout.C, self.D, self.k, self.alias, _ptr(out), None, None, self.ws.data_ptr(),
+                                  self.ws.numel(), _stream()), "ddg_attn_fill")
+        return out

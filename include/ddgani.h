@@ -191,6 +191,23 @@ int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset
                        int C, int D, int64_t k, float *out_code, float *out_tau, int32_t *out_nvalid,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* The three phases of ddg_attn_topk_fill, separately callable on the same workspace (same
+ * reference lines; used to time the phases and, multi-GPU, to prepare once per all-gather):
+ *   prepare: padded operands + per-column key / query index lists      (utils/util.py:439-448)
+ *   select : tau = k-th largest logit, smax = largest logit            (utils/util.py:452-462)
+ *   fill   : softmax over {s >= tau}, P^T X0, mask-merge               (utils/util.py:463-496)
+ * queries_alias_keys: 1 when prepare was called with identical query / key arrays. */
+int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
+                     const uint8_t *mk, const float *W, const int32_t *offsets_host,
+                     int64_t n_query_rows, int64_t n_key_rows, int C, int D,
+                     void *workspace, size_t workspace_bytes, void *stream);
+int ddg_attn_select(int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k,
+                    int queries_alias_keys, void *workspace, size_t workspace_bytes, void *stream);
+int ddg_attn_fill(const float *Xq0, const int32_t *offsets_host, int64_t n_query_rows,
+                  int64_t n_key_rows, int C, int D, int64_t k, int queries_alias_keys,
+                  float *out_code, float *out_tau, int32_t *out_nvalid,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
