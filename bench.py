@@ -136,9 +136,9 @@ def main():
             plan = ops.AttnPlan(Xq, mq, Xq, mq, tab.W, lay, k)
         plan.prepare()
         e[1].record()
-        plan.select()
+        plan.select(out=out_code)
         e[2].record()
-        plan.fill(out=out_code)
+        plan.fill()
         e[3].record()
         if comm.on:
             x0_hat = ddist.sharded_reverse_sample(comm, ops, P, T, xd, Md, lay, N, seed=i)

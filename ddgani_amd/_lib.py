@@ -60,9 +60,9 @@ SIGNATURES = {
                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddg_attn_prepare": (C.c_int, [c_f32p, c_u8p, C.c_int64, c_f32p, c_u8p, c_f32p, C.POINTER(C.c_int32), C.c_int64,
                                    C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "ddg_attn_select": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p,
-                                  C.c_size_t, C.c_void_p]),
-    "ddg_attn_fill": (C.c_int, [c_f32p, C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64,
+    "ddg_attn_select": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, c_f32p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_attn_fill": (C.c_int, [C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64,
                                 C.c_int, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

@@ -44,6 +44,7 @@ struct AttnArgs {
     float *tau, *smax;
     uint32_t *prefix;
     int32_t *rank;
+    int32_t *flag;             // [QB*128] MODE_TOPK: 1 = ties at the k-th logit, pair left to the MODE_FILL pass
     float *out_code;           // [Nq][D]
     float *out_tau;            // [Nq][C] or null
     int32_t *out_nvalid;       // [Nq][C] or null
@@ -66,13 +67,18 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __device__ __forceinline__ int level_shift(int L) { return L < 4 ? 25 - 7 * L : 0; }
 __device__ __forceinline__ int level_bits(int L) { return L < 4 ? 7 : 4; }
 
+// sorted (descending) insertion that carries the key position along with the logit
 template <int KCAP>
-__device__ __forceinline__ void list_insert(float (&lst)[KCAP], float v) {
+__device__ __forceinline__ void list_insert_kv(float (&lst)[KCAP], int (&pos)[KCAP], float v, int q) {
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) {
-        const float hi = fmaxf(lst[i], v);
-        v = fminf(lst[i], v);
-        lst[i] = hi;
+        const bool gt = v > lst[i];
+        const float lv = lst[i];
+        const int lq = pos[i];
+        lst[i] = gt ? v : lv;
+        pos[i] = gt ? q : lq;
+        v = gt ? lv : v;
+        q = gt ? lq : q;
     }
 }
 
@@ -128,15 +134,21 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     }
 
     // ---- per-mode state
+    // MODE_TOPK tracks the k+1 largest logits (and their positions in the key list): slots
+    // [ndummy, KCAP) are real, so the k-th largest ends in lst[KCAP-2] and the (k+1)-th in lst[KCAP-1]
     float lst[KCAP];
+    int lpos[KCAP];
     float smax = -INFINITY;
     float tau = 0.f, Z = 0.f, acc1 = 0.f;
     uint32_t prefix = 0;
     bool active = true;
-    if (MODE == MODE_TOPK) {
-        const int ndummy = KCAP - p.k;
+    if constexpr (MODE == MODE_TOPK) {
+        const int ndummy = KCAP - (p.k + 1);
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) lst[i] = (i < ndummy) ? INFINITY : -INFINITY;
+        for (int i = 0; i < KCAP; ++i) {
+            lst[i] = (i < ndummy) ? INFINITY : -INFINITY;
+            lpos[i] = -1;
+        }
     }
     if (MODE == MODE_HIST) {
         uint32_t *hist = reinterpret_cast<uint32_t *>(extra);
@@ -196,16 +208,15 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         const int rem = nk - t * TK;          // valid key rows in this tile (>= 1)
         const bool full = rem >= TK;
 
-        if (MODE == MODE_TOPK) {
+        if constexpr (MODE == MODE_TOPK) {
             float thr = lst[KCAP - 1];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
                 float v = acc[g];
                 if (!full && kr >= rem) v = -INFINITY;
-                smax = fmaxf(smax, v);
                 if (__any(v > thr)) {
-                    list_insert<KCAP>(lst, v);
+                    list_insert_kv<KCAP>(lst, lpos, v, t * TK + kr);
                     thr = lst[KCAP - 1];
                 }
             }
@@ -251,17 +262,47 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     }
 
     // ---- per-mode finish
-    if (MODE == MODE_TOPK) {
-        const int ndummy = KCAP - p.k;
-        float other[KCAP];
+    if constexpr (MODE == MODE_TOPK) {
+        // merge the two half-wave lists of each query, then (lanes h == 0) softmax over the kept k
+        // entries and gather their column-c values: the fill without a second similarity pass
+        const int ndummy = KCAP - (p.k + 1);
+        float ov[KCAP];
+        int op[KCAP];
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) other[i] = __shfl_xor(lst[i], 32);
+        for (int i = 0; i < KCAP; ++i) {
+            ov[i] = __shfl_xor(lst[i], 32);
+            op[i] = __shfl_xor(lpos[i], 32);
+        }
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) list_insert<KCAP>(lst, (i >= ndummy) ? other[i] : -INFINITY);
-        smax = fmaxf(smax, __shfl_xor(smax, 32));
-        if (h == 0) {
-            p.tau[slot] = lst[KCAP - 1];
-            p.smax[slot] = smax;
+        for (int i = 0; i < KCAP; ++i) list_insert_kv<KCAP>(lst, lpos, (i >= ndummy) ? ov[i] : -INFINITY, op[i]);
+        if (h == 0 && qrow >= 0) {
+            const bool tie = nk > p.k && lst[KCAP - 1] == lst[KCAP - 2];
+            p.tau[slot] = (nk >= p.k) ? lst[KCAP - 2] : -INFINITY;
+            float vmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < KCAP - 1; ++i)
+                if (i >= ndummy) vmax = fmaxf(vmax, lst[i]);
+            p.smax[slot] = vmax;
+            p.flag[slot] = tie ? 1 : 0;
+            if (!tie) {
+                float wgt[KCAP];
+                float Zs = 0.f;
+#pragma unroll
+                for (int i = 0; i < KCAP - 1; ++i) {
+                    const bool kept = i >= ndummy && lpos[i] >= 0;
+                    wgt[i] = kept ? expf(lst[i] - vmax) : 0.f;
+                    Zs += wgt[i];
+                    lpos[i] = kept ? kl[lpos[i]] : -1;      // key position -> key row
+                }
+                float *dst = p.out_code + (int64_t)qrow * p.D + off_c;
+                for (int e = 0; e < d_c; ++e) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < KCAP - 1; ++i)
+                        if (lpos[i] >= 0) a += wgt[i] * p.Xkp[(int64_t)lpos[i] * DP + off_c + e];
+                    dst[e] = (Zs > 0.f) ? a / Zs : 0.f;
+                }
+            }
         }
     } else if (MODE == MODE_HIST) {
         smax = fmaxf(smax, __shfl_xor(smax, 32));
@@ -401,6 +442,80 @@ __global__ void k_fill_lists(const uint8_t *__restrict__ m, int64_t rows, int C,
 }
 
 // ---------------------------------------------------------------------------------------------
+// tie fallback of the register path: pairs whose k-th and (k+1)-th logits are equal (flag == 1)
+// are compacted into a second query list, one block = 128 pairs of ONE column as before, and go
+// through the MODE_FILL pass.  cnt2[c] = flagged pairs of column c, cur2[c] = append cursor.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_column(const int32_t *qb_start, int C, int b) {
+    int lo = 0, hi = C;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (qb_start[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool WRITE>
+__global__ void k_compact_flagged(const int32_t *__restrict__ flag, const int32_t *__restrict__ qlist,
+                                  const float *__restrict__ tau, const float *__restrict__ smax,
+                                  const int32_t *__restrict__ qb_start, int C, int32_t *__restrict__ cnt2,
+                                  int32_t *__restrict__ cur2, const int32_t *__restrict__ qb_start2,
+                                  int32_t *__restrict__ qlist2, float *__restrict__ tau2, float *__restrict__ smax2) {
+    __shared__ int s_base, s_n;
+    if ((int)blockIdx.x >= qb_start[C]) return;
+    const int c = block_column(qb_start, C, blockIdx.x);
+    const int64_t slot = (int64_t)blockIdx.x * QPB + threadIdx.x;       // blockDim.x == QPB
+    const int q = qlist[slot];
+    const bool f = q >= 0 && flag[slot] != 0;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const unsigned long long b = __ballot(f);
+    int wbase = 0;
+    if (lane == 0 && b) wbase = atomicAdd(&s_n, __popcll(b));
+    wbase = __shfl(wbase, 0);
+    __syncthreads();
+    if (s_n == 0) return;
+    if (!WRITE) {
+        if (threadIdx.x == 0) atomicAdd(&cnt2[c], s_n);
+        return;
+    }
+    if (threadIdx.x == 0) s_base = atomicAdd(&cur2[c], s_n);
+    __syncthreads();
+    if (f) {
+        const int64_t d = (int64_t)qb_start2[c] * QPB + s_base + wbase + __popcll(b & ((1ull << lane) - 1ull));
+        qlist2[d] = q;
+        tau2[d] = tau[slot];
+        smax2[d] = smax[slot];
+    }
+}
+
+// qb_start2[c] = sum_{c'<c} ceil(cnt2[c']/128)
+__global__ void k_qb_start2(const int32_t *__restrict__ cnt2, int C, int32_t *__restrict__ qb_start2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < C; ++c) {
+            qb_start2[c] = run;
+            run += (cnt2[c] + QPB - 1) / QPB;
+        }
+        qb_start2[C] = run;
+    }
+}
+
+// debug outputs of the register path: tau and the number of valid keys per (row, column) pair
+__global__ void k_write_debug(const int32_t *__restrict__ qlist, const float *__restrict__ tau,
+                              const int32_t *__restrict__ qb_start, const int32_t *__restrict__ nk, int C,
+                              float *__restrict__ out_tau, int32_t *__restrict__ out_nvalid) {
+    if ((int)blockIdx.x >= qb_start[C]) return;
+    const int c = block_column(qb_start, C, blockIdx.x);
+    const int64_t slot = (int64_t)blockIdx.x * QPB + threadIdx.x;
+    const int q = qlist[slot];
+    if (q < 0) return;
+    if (out_tau) out_tau[(int64_t)q * C + c] = tau[slot];
+    if (out_nvalid) out_nvalid[(int64_t)q * C + c] = nk[c];
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -413,6 +528,9 @@ struct AttnWs {
     uint32_t *prefix;
     int32_t *rank;
     int32_t *flags;            // [0] = 1 when queries alias keys (set by prepare)
+    // tie fallback of the register path
+    int32_t *flag, *qlist2, *qb_start2, *cnt2;   // cnt2: [C] counts then [C] cursors
+    float *tau2, *smax2;
     size_t total;
     int64_t qb_max;
     int nchunk_k, nchunk_q;
@@ -443,6 +561,12 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
     w.prefix = (uint32_t *)take((size_t)w.qb_max * QPB * 4);
     w.rank = (int32_t *)take((size_t)w.qb_max * QPB * 4);
     w.flags = (int32_t *)take(256);
+    w.flag = (int32_t *)take((size_t)w.qb_max * QPB * 4);
+    w.qlist2 = (int32_t *)take((size_t)w.qb_max * QPB * 4);
+    w.tau2 = (float *)take((size_t)w.qb_max * QPB * 4);
+    w.smax2 = (float *)take((size_t)w.qb_max * QPB * 4);
+    w.qb_start2 = (int32_t *)take((size_t)(C + 1) * 4);
+    w.cnt2 = (int32_t *)take((size_t)2 * C * 4);
     w.total = o;
 }
 
@@ -476,8 +600,8 @@ static int launch_attn(const AttnArgs &a, int64_t qb_max, size_t extra_bytes, hi
 template <int KS4>
 static int run_select(AttnArgs &a, int64_t qb_max, hipStream_t s) {
     int rc;
-    if (a.k <= 16) return launch_attn<KS4, MODE_TOPK, 16>(a, qb_max, 0, s);
-    if (a.k <= 32) return launch_attn<KS4, MODE_TOPK, 32>(a, qb_max, 0, s);
+    if (a.k < 16) return launch_attn<KS4, MODE_TOPK, 16>(a, qb_max, 0, s);
+    if (a.k <= DDG_MAX_TOPK_REG) return launch_attn<KS4, MODE_TOPK, 32>(a, qb_max, 0, s);
     for (int L = 0; L < 5; ++L) {
         a.level = L;
         rc = launch_attn<KS4, MODE_HIST, 1>(a, qb_max, (size_t)QPB * HSTRIDE * 4, s);
@@ -501,7 +625,7 @@ static int attn_check_dims(int64_t Nq, int64_t Nk, int C, int D) {
 static void attn_args(AttnArgs &a, const AttnWs &w, int64_t Nk, int C, int D, int k) {
     a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.klist = w.klist; a.nk = w.nk; a.qlist = w.qlist;
     a.qb_start = w.qb_start; a.offsets = w.offsets; a.tau = w.tau; a.smax = w.smax; a.prefix = w.prefix;
-    a.rank = w.rank; a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
+    a.rank = w.rank; a.flag = w.flag; a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
     a.D = D; a.DP = ks4_for(D) * 8; a.k = k; a.level = 0; a.dcs = 1;
 }
 
@@ -550,9 +674,15 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
     return DDG_OK;
 }
 
-// phase 2: k-th largest logit (tau) and the largest logit per (query row, column) pair
-extern "C" int ddg_attn_select(int64_t Nq, int64_t Nk, int C, int D, int64_t k, int queries_alias_keys,
-                               void *workspace, size_t workspace_bytes, void *stream) {
+// phase 2: one similarity pass.  out_code <- Xq0, then
+//   k <= DDG_MAX_TOPK_REG: the k+1 largest logits and their key rows per (query row, column) pair
+//     in registers; pairs without a tie at the k-th logit are filled right here (softmax over
+//     the kept k, gather of the key values), the others are flagged for phase 3;
+//   larger k: 5-level radix select of tau (5 similarity passes), every pair is filled in phase 3.
+extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, int D, int64_t k,
+                               int queries_alias_keys, float *out_code, void *workspace, size_t workspace_bytes,
+                               void *stream) {
+    if (!Xq0 || !out_code) return DDG_E_ARG;
     int rc = attn_check_dims(Nq, Nk, C, D);
     if (rc) return rc;
     if (k < 1) return DDG_E_ARG;
@@ -560,9 +690,13 @@ extern "C" int ddg_attn_select(int64_t Nq, int64_t Nk, int C, int D, int64_t k, 
     AttnWs w;
     attn_carve(w, (char *)workspace, Nq, Nk, C, D, queries_alias_keys != 0);
     if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_code != Xq0 &&
+        hipMemcpyAsync(out_code, Xq0, (size_t)Nq * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return DDG_E_LAUNCH;
     AttnArgs a;
     attn_args(a, w, Nk, C, D, (int)(k > Nk ? Nk : k));
-    hipStream_t s = (hipStream_t)stream;
+    a.out_code = out_code;
     switch (ks4_for(D)) {
         case 8: return run_select<8>(a, w.qb_max, s);
         case 16: return run_select<16>(a, w.qb_max, s);
@@ -572,13 +706,15 @@ extern "C" int ddg_attn_select(int64_t Nq, int64_t Nk, int C, int D, int64_t k, 
     return DDG_E_UNSUPPORTED;
 }
 
-// phase 3: softmax-weighted accumulation over {s >= tau} and mask-merge into out_code
-extern "C" int ddg_attn_fill(const float *Xq0, const int32_t *offsets_host, int64_t Nq, int64_t Nk, int C, int D,
-                             int64_t k, int queries_alias_keys, float *out_code, float *out_tau,
-                             int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!Xq0 || !offsets_host || !out_code) return DDG_E_ARG;
+// phase 3: softmax-weighted accumulation over {s >= tau} (second similarity pass) for the pairs
+// phase 2 left open: all of them on the radix path, only the tie-flagged ones on the register path
+extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk, int C, int D, int64_t k,
+                             int queries_alias_keys, float *out_code, float *out_tau, int32_t *out_nvalid,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    if (!offsets_host || !out_code) return DDG_E_ARG;
     int rc = attn_check_dims(Nq, Nk, C, D);
     if (rc) return rc;
+    if (k < 1) return DDG_E_ARG;
     if (Nq == 0) return DDG_OK;
     int dcmax = 1;
     for (int c = 0; c < C; ++c) {
@@ -590,12 +726,25 @@ extern "C" int ddg_attn_fill(const float *Xq0, const int32_t *offsets_host, int6
     attn_carve(w, (char *)workspace, Nq, Nk, C, D, queries_alias_keys != 0);
     if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    if (out_code != Xq0 &&
-        hipMemcpyAsync(out_code, Xq0, (size_t)Nq * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return DDG_E_LAUNCH;
     AttnArgs a;
-    attn_args(a, w, Nk, C, D, (int)(k > Nk ? Nk : k));
+    const int kk = (int)(k > Nk ? Nk : k);
+    attn_args(a, w, Nk, C, D, kk);
     a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
+    if (kk <= DDG_MAX_TOPK_REG) {
+        const unsigned g = (unsigned)w.qb_max;
+        if (hipMemsetAsync(w.cnt2, 0, (size_t)2 * C * 4, s) != hipSuccess) return DDG_E_LAUNCH;
+        if (hipMemsetAsync(w.qlist2, 0xFF, (size_t)w.qb_max * QPB * 4, s) != hipSuccess) return DDG_E_LAUNCH;
+        k_compact_flagged<false><<<g, QPB, 0, s>>>(w.flag, w.qlist, w.tau, w.smax, w.qb_start, C, w.cnt2, w.cnt2 + C,
+                                                   w.qb_start2, w.qlist2, w.tau2, w.smax2);
+        k_qb_start2<<<1, 64, 0, s>>>(w.cnt2, C, w.qb_start2);
+        k_compact_flagged<true><<<g, QPB, 0, s>>>(w.flag, w.qlist, w.tau, w.smax, w.qb_start, C, w.cnt2, w.cnt2 + C,
+                                                  w.qb_start2, w.qlist2, w.tau2, w.smax2);
+        if (out_tau || out_nvalid)
+            k_write_debug<<<g, QPB, 0, s>>>(w.qlist, w.tau, w.qb_start, w.nk, C, out_tau, out_nvalid);
+        DDG_CHECK_LAUNCH();
+        a.qlist = w.qlist2; a.qb_start = w.qb_start2; a.tau = w.tau2; a.smax = w.smax2;
+        a.out_tau = nullptr; a.out_nvalid = nullptr;
+    }
     switch (ks4_for(D)) {
         case 8: return run_fill<8>(a, w.qb_max, dcmax, s);
         case 16: return run_fill<16>(a, w.qb_max, dcmax, s);
@@ -614,8 +763,8 @@ extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q
                               workspace_bytes, stream);
     if (rc) return rc;
     const int same = (Xq0 == Xk0 && mq == mk && Nq == Nk) ? 1 : 0;
-    rc = ddg_attn_select(Nq, Nk, C, D, k, same, workspace, workspace_bytes, stream);
+    rc = ddg_attn_select(Xq0, Nq, Nk, C, D, k, same, out_code, workspace, workspace_bytes, stream);
     if (rc) return rc;
-    return ddg_attn_fill(Xq0, offsets_host, Nq, Nk, C, D, k, same, out_code, out_tau, out_nvalid, workspace,
+    return ddg_attn_fill(offsets_host, Nq, Nk, C, D, k, same, out_code, out_tau, out_nvalid, workspace,
                          workspace_bytes, stream);
 }

@@ -294,14 +294,23 @@ class AttnPlan:
                                      self.layout.C, self.D, self.ws.data_ptr(), self.ws.numel(), _stream()),
               "ddg_attn_prepare")
 
-    def select(self):
-        check(lib().ddg_attn_select(self.Nq, self.Nk, self.layout.C, self.D, self.k, self.alias, self.ws.data_ptr(),
-                                    self.ws.numel(), _stream()), "ddg_attn_select")
-
-    def fill(self, out=None):
+    def select(self, out=None):
+        """one similarity pass; k <= 31 also fills every pair without a tie at the k-th logit"""
         if out is None:
             out = torch.empty_like(self.Xq0)
-        check(lib().ddg_attn_fill(_ptr(self.Xq0, torch.float32), self.layout.offsets_host, self.Nq, self.Nk,
-                                  self.layout.C, self.D, self.k, self.alias, _ptr(out), None, None, self.ws.data_ptr(),
-                                  self.ws.numel(), _stream()), "ddg_attn_fill")
+        self.out = out
+        check(lib().ddg_attn_select(_ptr(self.Xq0, torch.float32), self.Nq, self.Nk, self.layout.C, self.D, self.k,
+                                    self.alias, _ptr(out), self.ws.data_ptr(), self.ws.numel(), _stream()),
+              "ddg_attn_select")
         return out
+
+    def fill(self, debug: bool = False):
+        """the pairs select() left open (tie-flagged, or all of them when k > 31)"""
+        tau = nval = None
+        if debug:
+            tau = torch.full((self.Nq, self.layout.C), float("nan"), dtype=torch.float32, device=self.out.device)
+            nval = torch.full((self.Nq, self.layout.C), -1, dtype=torch.int32, device=self.out.device)
+        check(lib().ddg_attn_fill(self.layout.offsets_host, self.Nq, self.Nk, self.layout.C, self.D, self.k,
+                                  self.alias, _ptr(self.out), _ptr(tau), _ptr(nval), self.ws.data_ptr(),
+                                  self.ws.numel(), _stream()), "ddg_attn_fill")
+        return (self.out, tau, nval) if debug else self.out

@@ -37,7 +37,7 @@ extern "C" {
 #define DDG_E_LAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch             */
 
 #define DDG_MAX_D 256         /* widest encoded table the attention kernels are built for   */
-#define DDG_MAX_TOPK_REG 32   /* absolute k up to this uses the in-register selection       */
+#define DDG_MAX_TOPK_REG 31   /* absolute k up to this uses the in-register selection       */
 
 /* library / error helpers */
 int ddg_version(void);
@@ -179,8 +179,9 @@ int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const float *xt, 
  * (q_row_offset = global index of its first row); keys are all rows (after the all-gather
  * in the multi-GPU case).  On one GPU pass the same pointers for queries and keys.
  * mq/mk: uint8 0/1 [rows,C].  W: [C,D].  offsets: int32[C+1] on the HOST here.
- * k >= 1.  k <= DDG_MAX_TOPK_REG selects in registers (one similarity pass + one fill pass);
- * larger k uses an exact 5-level radix select on the logits (5 similarity passes + fill).
+ * k >= 1.  k <= DDG_MAX_TOPK_REG selects AND fills in registers (one similarity pass; pairs with
+ * an exact tie at the k-th logit take a second one); larger k uses an exact 5-level radix select
+ * on the logits (5 similarity passes + a fill pass).
  * Optional debug outputs (NULL to skip): out_tau [Nq,C] (NaN where mq==1, -inf when all
  * valid keys are kept), out_nvalid int32 [Nq,C].
  * ------------------------------------------------------------------------------------- */
@@ -194,18 +195,25 @@ int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset
 /* The three phases of ddg_attn_topk_fill, separately callable on the same workspace (same
  * reference lines; used to time the phases and, multi-GPU, to prepare once per all-gather):
  *   prepare: padded operands + per-column key / query index lists      (utils/util.py:439-448)
- *   select : tau = k-th largest logit, smax = largest logit            (utils/util.py:452-462)
- *   fill   : softmax over {s >= tau}, P^T X0, mask-merge               (utils/util.py:463-496)
+ *   select : out_code <- Xq0, then ONE similarity pass                 (utils/util.py:452-466)
+ *            k <= DDG_MAX_TOPK_REG: the k+1 largest logits and their key rows are kept in
+ *            registers; every pair whose k-th and (k+1)-th logits differ is filled right there
+ *            (softmax over the kept k, gather of the key values: utils/util.py:484-496), pairs
+ *            with a tie at the k-th logit are flagged for the fill phase;
+ *            larger k: exact 5-level radix select of tau (5 similarity passes)
+ *   fill   : softmax over {s >= tau}, P^T X0, mask-merge (one more similarity pass) for the
+ *            pairs select left open: the flagged ones, or all of them on the radix path
+ *                                                                      (utils/util.py:463-496)
  * queries_alias_keys: 1 when prepare was called with identical query / key arrays. */
 int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
                      const uint8_t *mk, const float *W, const int32_t *offsets_host,
                      int64_t n_query_rows, int64_t n_key_rows, int C, int D,
                      void *workspace, size_t workspace_bytes, void *stream);
-int ddg_attn_select(int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k,
-                    int queries_alias_keys, void *workspace, size_t workspace_bytes, void *stream);
-int ddg_attn_fill(const float *Xq0, const int32_t *offsets_host, int64_t n_query_rows,
-                  int64_t n_key_rows, int C, int D, int64_t k, int queries_alias_keys,
-                  float *out_code, float *out_tau, int32_t *out_nvalid,
+int ddg_attn_select(const float *Xq0, int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k,
+                    int queries_alias_keys, float *out_code, void *workspace, size_t workspace_bytes,
+                    void *stream);
+int ddg_attn_fill(const int32_t *offsets_host, int64_t n_query_rows, int64_t n_key_rows, int C, int D,
+                  int64_t k, int queries_alias_keys, float *out_code, float *out_tau, int32_t *out_nvalid,
                   void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
