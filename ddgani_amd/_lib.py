@@ -30,6 +30,23 @@ class DiscWeights(C.Structure):
                [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "e1", "e2", "e3")]
 
 
+class TrainBatch(C.Structure):
+    """struct ddg_train_batch (include/ddgani.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("x0", "M", "m", "t", "eps", "drop0", "drop1", "drop2")] + \
+               [("drop_p", C.c_float), ("seed", C.c_uint64), ("stream_id", C.c_uint64), ("rows", C.c_int64)]
+
+
+class GenGrads(C.Structure):
+    """struct ddg_gen_grads (include/ddgani.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2",
+                                          "W3", "b3", "g3", "be3", "W4", "b4", "temb")]
+
+
+class DiscGrads(C.Structure):
+    """struct ddg_disc_grads (include/ddgani.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "e1", "e2", "e3")]
+
+
 # name -> (restype, argtypes); every symbol include/ddgani.h declares
 SIGNATURES = {
     "ddg_version": (C.c_int, []),
@@ -54,6 +71,16 @@ SIGNATURES = {
     "ddg_disc_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "ddg_disc_fwd": (C.c_int, [C.POINTER(DiscWeights), c_f32p, c_f32p, c_i64p, C.c_int, c_f32p, C.c_int64,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_train_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddg_train_gen_grads": (C.c_int, [C.POINTER(GenWeights), C.POINTER(DiscWeights), C.POINTER(TrainBatch), c_f32p,
+                                      C.c_int, c_i32p, c_u8p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                      C.POINTER(GenGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_train_disc_grads": (C.c_int, [C.POINTER(GenWeights), C.POINTER(DiscWeights), C.POINTER(TrainBatch), c_f32p,
+                                       C.c_int, c_i32p, c_u8p, C.c_int, C.c_float, C.c_float,
+                                       C.POINTER(DiscGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double, C.c_double,
+                                C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "ddg_attn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64]),
     "ddg_attn_topk_fill": (C.c_int, [c_f32p, c_u8p, C.c_int64, c_f32p, c_u8p, c_f32p, C.POINTER(C.c_int32),
                                      C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, c_f32p, c_f32p, c_i32p,

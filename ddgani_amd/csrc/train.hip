@@ -1,0 +1,609 @@
+// Training side of the hot path at the reference's minibatch size (B = 128 rows): forward with
+// saved activations, the three losses, hand-written backward of the denoiser and of the
+// time-conditioned discriminator, and torch.optim.Adam.  gfx950 only.
+//
+// Reference functions restated (relative to the reference tree):
+//   train_one_epoch_Generator                 model/Diffusion.py:245-318   (one step = :287-311)
+//   train_one_epoch_discriminator_noise_x     model/Diffusion.py:321-379   (one step = :356-372)
+//   res_loss_func / G_d_loss_func / D_loss_func   model/Diffusion.py:452-526
+//   optim.Adam(G, lr 1e-4, wd 1e-4) / optim.Adam(Dn, lr 1e-4)   model/Diffusion.py:571-573
+//
+// What autograd does in the reference is written out here layer by layer.  All GEMMs (forward
+// Y = A W^T, input gradients dA = dY W, weight gradients dW = dY^T A) run on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32): the step is 128 rows deep, so every GEMM is a handful of 32x32 tiles
+// and the step is launch-latency bound (about 50 short kernels); callers capture it in a HIP graph.
+#include <math.h>
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// generic small GEMM, one wave per 32x32 tile of C:  C[m,n] = sum_k A(m,k) * B(k,n)
+// with element strides (sam, sak) / (sbk, sbn), so the same kernel serves NN, NT and TN.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gemm_small(const float *__restrict__ A, int64_t sam, int64_t sak,
+                                                    const float *__restrict__ B, int64_t sbk, int64_t sbn,
+                                                    float *__restrict__ Cm, int64_t ldc, int M, int N, int K) {
+    const int lane = threadIdx.x, r32 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m = m0 + r32, n = n0 + r32;
+    const bool mok = m < M, nok = n < N;
+    const float *Ap = A + (int64_t)(mok ? m : 0) * sam;
+    const float *Bp = B + (int64_t)(nok ? n : 0) * sbn;
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k + 2 * u + h;
+            a[u] = mok ? Ap[(int64_t)kk * sak] : 0.f;
+            b[u] = nok ? Bp[(int64_t)kk * sbk] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k < K; k += 2) {
+        const int kk = k + h;
+        const float a = (mok && kk < K) ? Ap[(int64_t)kk * sak] : 0.f;
+        const float b = (nok && kk < K) ? Bp[(int64_t)kk * sbk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (nok) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int row = m0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (row < M) Cm[(int64_t)row * ldc + n] = acc[g];
+        }
+    }
+}
+
+static int gemm_small(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *Cm,
+                      int64_t ldc, int M, int N, int K, hipStream_t s) {
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+    k_gemm_small<<<grid, 64, 0, s>>>(A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+// dA[B,in] = dY[B,out] * W[out,in]
+static int gemm_dA(const float *dY, const float *W, float *dA, int rows, int in, int out, hipStream_t s) {
+    return gemm_small(dY, out, 1, W, in, 1, dA, in, rows, in, out, s);
+}
+// dW[out,in] = dY[B,out]^T * H[B,in]
+static int gemm_dW(const float *dY, const float *H, float *dW, int rows, int in, int out, hipStream_t s) {
+    return gemm_small(dY, 1, out, H, in, 1, dW, in, out, in, rows, s);
+}
+
+// out[col] = sum_r X[r,col]                                  (bias gradients)
+__global__ void k_colsum(const float *__restrict__ X, int rows, int N, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += X[(int64_t)r * N + c];
+    out[c] = s;
+}
+
+// out[s,col] = sum over rows r with t[r] == s of X[r, col]   (embedding gradients, dense like torch's)
+__global__ void k_emb_grad(const float *__restrict__ X, int64_t ldx, const int64_t *__restrict__ t, int rows, int N,
+                           int n_steps, float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_steps * N) return;
+    const int s = e / N, c = e - s * N;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r)
+        if ((int)t[r] == s) a += X[(int64_t)r * ldx + c];
+    out[e] = a;
+}
+
+// h0 = x_t + temb[t]
+__global__ void k_add_emb(const float *__restrict__ x, const float *__restrict__ emb, const int64_t *__restrict__ t,
+                          int rows, int D, float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * D) return;
+    const int r = e / D, k = e - r * D;
+    out[e] = x[e] + emb[(int64_t)t[r] * D + k];
+}
+
+// BatchNorm(train) + ReLU + Dropout, forward, with the gate (0 or 1/(1-p) where the unit is on) saved
+__global__ void k_bn_act_fwd(const float *__restrict__ z, const float *__restrict__ scale,
+                             const float *__restrict__ shift, const uint8_t *__restrict__ drop, float drop_p,
+                             uint64_t seed, uint64_t stream_id, int rows, int width, float *__restrict__ hout,
+                             float *__restrict__ gate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * width) return;
+    const int k = e % width;
+    const float bn = z[e] * scale[k] + shift[k];
+    float g = bn > 0.f ? 1.f : 0.f;
+    const float keep_scale = 1.f / (1.f - drop_p);
+    if (drop) {
+        g = drop[e] ? g * keep_scale : 0.f;
+    } else if (drop_p > 0.f) {
+        const float u = philox_uniform4(seed, stream_id, (uint64_t)e >> 2)[e & 3];
+        g = (u > drop_p) ? g * keep_scale : 0.f;
+    }
+    hout[e] = fmaxf(bn, 0.f) * g;
+    gate[e] = g;
+}
+
+// backward of the above for one layer; one thread per column.
+//   da = dh * gate ; dbeta = sum da ; dgamma = sum da * xhat ; dz = gamma*invstd*(da - dbeta/B - xhat*dgamma/B)
+__global__ void k_bn_act_bwd(const float *__restrict__ dh, const float *__restrict__ gate, const float *__restrict__ z,
+                             const double *__restrict__ stats, const float *__restrict__ gamma, float eps, int rows,
+                             int width, float *__restrict__ dz, float *__restrict__ dgamma,
+                             float *__restrict__ dbeta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= width) return;
+    const double mean_d = stats[k] / rows;
+    double var = stats[width + k] / rows - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = (float)mean_d;
+    float sda = 0.f, sdx = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const int64_t e = (int64_t)r * width + k;
+        const float da = dh[e] * gate[e];
+        sda += da;
+        sdx += da * ((z[e] - mean) * invstd);
+    }
+    dgamma[k] = sdx;
+    dbeta[k] = sda;
+    const float gi = gamma[k] * invstd, inv_n = 1.f / (float)rows;
+    for (int r = 0; r < rows; ++r) {
+        const int64_t e = (int64_t)r * width + k;
+        const float da = dh[e] * gate[e];
+        const float xh = (z[e] - mean) * invstd;
+        dz[e] = gi * (da - sda * inv_n - xh * sdx * inv_n);
+    }
+}
+
+// discriminator hidden activation r = relu(a + e[t]) and its backward
+__global__ void k_emb_relu_fwd(const float *__restrict__ a, const float *__restrict__ emb,
+                               const int64_t *__restrict__ t, int rows, int width, float *__restrict__ r_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * width) return;
+    const int r = e / width, k = e - r * width;
+    r_out[e] = fmaxf(a[e] + emb[(int64_t)t[r] * width + k], 0.f);
+}
+__global__ void k_relu_bwd(const float *__restrict__ dr, const float *__restrict__ r_act, int n,
+                           float *__restrict__ da) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    da[e] = r_act[e] > 0.f ? dr[e] : 0.f;
+}
+
+// x_{t-1} of G_d_loss_func / D_loss_func (model/Diffusion.py:487-502), reference op order
+#pragma clang fp contract(off)
+__global__ void k_xtj1_train(const float *__restrict__ pred, const float *__restrict__ xt,
+                             const float *__restrict__ x0, const float *__restrict__ eps,
+                             const float *__restrict__ M, const int64_t *__restrict__ t,
+                             const float *__restrict__ sched, int T, int rows, int D, float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * D) return;
+    const int r = e / D;
+    const int ti = (int)t[r];
+    const float *betas = sched, *sa = sched + 2 * T, *ac = sched + 5 * T, *sac = sched + 6 * T, *s1m = sched + 7 * T;
+    const float o = sac[ti - 2] * x0[e] + s1m[ti - 2] * eps[e];
+    const float one_m = 1.f - ac[ti - 2];
+    const float den = 1.f - ac[ti - 1];
+    const float gm = (sac[ti - 2] * betas[ti - 1] * pred[e] + sa[ti - 1] * one_m * xt[e]) / den;
+    const float gs = one_m * betas[ti - 1] * eps[e] / den;
+    const float g = gm + gs;
+    out[e] = M[e] * o + (1.f - M[e]) * g;
+}
+#pragma clang fp contract(on)
+
+// res_loss_func (model/Diffusion.py:452-484): value and gradient w.r.t. the prediction.  One block.
+__global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__restrict__ x0,
+                                const float *__restrict__ M, const int32_t *__restrict__ offsets,
+                                const uint8_t *__restrict__ is_cat, int C, int rows, int D,
+                                float *__restrict__ dpred, float *__restrict__ loss_out) {
+    extern __shared__ int sh_i[];
+    int *ngood = sh_i;                       // [C]
+    __shared__ double lsum[2];
+    __shared__ int nfield[2];
+    for (int f = threadIdx.x; f < C; f += blockDim.x) ngood[f] = 0;
+    if (threadIdx.x == 0) {
+        lsum[0] = lsum[1] = 0.0;
+        int nn = 0, nc = 0;
+        for (int f = 0; f < C; ++f) { if (is_cat[f]) ++nc; else ++nn; }
+        nfield[0] = nn > 0 ? nn : 1;
+        nfield[1] = nc > 0 ? nc : 1;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
+        const int r = w / C, f = w - r * C;
+        bool good = true;
+        for (int j = offsets[f]; j < offsets[f + 1]; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
+        if (good) atomicAdd(&ngood[f], 1);
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
+        const int r = w / C, f = w - r * C;
+        const int a = offsets[f], b = offsets[f + 1];
+        bool good = true;
+        for (int j = a; j < b; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
+        const float *p = pred + (int64_t)r * D, *x = x0 + (int64_t)r * D;
+        float *dp = dpred + (int64_t)r * D;
+        if (!good) {
+            for (int j = a; j < b; ++j) dp[j] = 0.f;
+            continue;
+        }
+        const float ng = (float)ngood[f];
+        if (!is_cat[f]) {
+            const float nel = ng * (float)(b - a);
+            double l = 0.0;
+            for (int j = a; j < b; ++j) {
+                const float d = p[j] - x[j];
+                dp[j] = 2.f * d / (nel * (float)nfield[0]);
+                l += (double)d * d;
+            }
+            atomicAdd(&lsum[0], l / (double)nel);
+        } else {
+            float s = 0.f;
+            for (int j = a; j < b; ++j) s += (p[j] + 1e-6f) * x[j];
+            s += 1e-6f;
+            for (int j = a; j < b; ++j) dp[j] = -x[j] / s / (ng * (float)nfield[1]);
+            atomicAdd(&lsum[1], -(double)logf(s) / (double)ng);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (float)(lsum[0] / nfield[0] + lsum[1] / nfield[1]);
+}
+
+// discriminator output, loss and d(loss)/d(logit).  mode 0: G_d_loss_func (:504); mode 1: D_loss_func (:523)
+__global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__restrict__ m, int n, int mode,
+                                 float scale, float *__restrict__ da4, float *__restrict__ loss_out) {
+    __shared__ double part[256];
+    double l = 0.0;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const float d = 1.f / (1.f + expf(-a4[e]));
+        const float mm = m[e];
+        float dl;   // d loss_sum / d d
+        if (mode == 0) {
+            l += -(double)((1.f - mm) * logf(d + 1e-8f));
+            dl = -(1.f - mm) / (d + 1e-8f);
+        } else {
+            l += -(double)((1.f - mm) * logf(1.f - d + 1e-4f) + mm * logf(d + 1e-4f));
+            dl = (1.f - mm) / (1.f - d + 1e-4f) - mm / (d + 1e-4f);
+        }
+        da4[e] = scale * dl / (float)n * d * (1.f - d);
+    }
+    part[threadIdx.x] = l;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] = (float)(part[0] / n);
+}
+
+// total d(loss)/d(pred) = w_res * dres + dxtj1 * (1-M) * sqrt(abar_{t-1}) beta_t / (1-abar_t), then the
+// backward of the per-field head (sigmoid / softmax): one thread per (row, field)
+__global__ void k_head_bwd(const float *__restrict__ dres, float w_res, const float *__restrict__ dcat, int64_t ldcat,
+                           const float *__restrict__ M, const int64_t *__restrict__ t,
+                           const float *__restrict__ sched, int T, const float *__restrict__ pred,
+                           const int32_t *__restrict__ offsets, const uint8_t *__restrict__ is_cat, int C, int rows,
+                           int D, float *__restrict__ dy) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= rows * C) return;
+    const int r = w / C, f = w - r * C;
+    const int a = offsets[f], b = offsets[f + 1];
+    const int ti = (int)t[r];
+    const float coef = sched[6 * T + ti - 2] * sched[ti - 1] / (1.f - sched[5 * T + ti - 1]);
+    const float *p = pred + (int64_t)r * D;
+    auto dp = [&](int j) {
+        const int64_t e = (int64_t)r * D + j;
+        float v = dres ? w_res * dres[e] : 0.f;
+        if (dcat) v += dcat[(int64_t)r * ldcat + j] * (1.f - M[e]) * coef;
+        return v;
+    };
+    if (is_cat[f]) {
+        float dot = 0.f;
+        for (int j = a; j < b; ++j) dot += dp(j) * p[j];
+        for (int j = a; j < b; ++j) dy[(int64_t)r * D + j] = p[j] * (dp(j) - dot);
+    } else {
+        for (int j = a; j < b; ++j) dy[(int64_t)r * D + j] = dp(j) * p[j] * (1.f - p[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// torch.optim.Adam (non-amsgrad, coupled L2), all tensors of a net in one launch
+// ---------------------------------------------------------------------------------------------
+#define ADAM_MAX_TENSORS 16
+struct AdamTable {
+    float *p[ADAM_MAX_TENSORS];
+    const float *g[ADAM_MAX_TENSORS];
+    float *m[ADAM_MAX_TENSORS];
+    float *v[ADAM_MAX_TENSORS];
+    int64_t n[ADAM_MAX_TENSORS];
+    int count;
+};
+
+#pragma clang fp contract(off)
+__global__ void k_adam(AdamTable tb, float step_size, float one_m_b1, float b2, float one_m_b2, float eps, float wd,
+                       float sqrt_bc2) {
+    const int ti = blockIdx.y;
+    if (ti >= tb.count) return;
+    float *p = tb.p[ti];
+    const float *g = tb.g[ti];
+    float *m = tb.m[ti], *v = tb.v[ti];
+    const int64_t n = tb.n[ti];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float gg = g[e];
+        if (wd != 0.f) gg = gg + wd * p[e];
+        // torch: exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, 1-b2)
+        const float mn = m[e] + one_m_b1 * (gg - m[e]);
+        const float vn = v[e] * b2 + one_m_b2 * gg * gg;
+        m[e] = mn;
+        v[e] = vn;
+        const float denom = sqrtf(vn) / sqrt_bc2 + eps;
+        p[e] = p[e] - step_size * (mn / denom);
+    }
+}
+#pragma clang fp contract(on)
+
+extern "C" int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                             float *const *exp_avg_sq, const int64_t *numel, int step, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, void *stream) {
+    if (n_tensors < 1 || n_tensors > ADAM_MAX_TENSORS || !params || !grads || !exp_avg || !exp_avg_sq || !numel ||
+        step < 1)
+        return DDG_E_ARG;
+    AdamTable tb;
+    int64_t nmax = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 0) return DDG_E_ARG;
+        tb.p[i] = params[i]; tb.g[i] = grads[i]; tb.m[i] = exp_avg[i]; tb.v[i] = exp_avg_sq[i]; tb.n[i] = numel[i];
+        if (numel[i] > nmax) nmax = numel[i];
+    }
+    tb.count = n_tensors;
+    // scalar prefactors in double like torch's Python-side arithmetic, tensors in fp32
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    int64_t gx = ceil_div64(nmax, 256);
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)n_tensors);
+    k_adam<<<grid, 256, 0, (hipStream_t)stream>>>(tb, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2,
+                                                  (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                                                  (float)sqrt(bc2));
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace of one training step
+// ---------------------------------------------------------------------------------------------
+static inline size_t tal(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct TrainWs {
+    float *xt, *h0, *z1, *h1, *g1, *z2, *h2, *g2, *z3, *h3, *g3, *y, *pred;
+    double *st[3];
+    float *sc[3], *sf[3];
+    float *xtj1, *a1, *r1, *a2, *r2, *a3, *r3, *a4, *da4, *dA, *dB, *dcat;
+    float *dres, *dy, *dh, *dz;
+    float *fwd_ws;             // workspace of ddg_denoiser_fwd (discriminator step)
+    size_t fwd_ws_bytes;
+    size_t total;
+};
+
+static void train_carve(TrainWs &w, char *base, int64_t B, int D, int E, int L, int H, int C) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + o : nullptr; o += tal(bytes); return p; };
+    const size_t mx = (size_t)(E > L ? E : L);
+    auto f = [&](size_t n) { return (float *)take(n * 4); };
+    w.xt = f(B * D); w.h0 = f(B * D);
+    w.z1 = f(B * E); w.h1 = f(B * E); w.g1 = f(B * E);
+    w.z2 = f(B * L); w.h2 = f(B * L); w.g2 = f(B * L);
+    w.z3 = f(B * E); w.h3 = f(B * E); w.g3 = f(B * E);
+    w.y = f(B * D); w.pred = f(B * D);
+    for (int i = 0; i < 3; ++i) w.st[i] = (double *)take(2 * mx * 8);
+    for (int i = 0; i < 3; ++i) { w.sc[i] = f(mx); w.sf[i] = f(mx); }
+    w.xtj1 = f(B * D);
+    w.a1 = f(B * H); w.r1 = f(B * H); w.a2 = f(B * H); w.r2 = f(B * H); w.a3 = f(B * H); w.r3 = f(B * H);
+    w.a4 = f(B * C); w.da4 = f(B * C); w.dA = f(B * H); w.dB = f(B * H); w.dcat = f(B * 2 * D);
+    w.dres = f(B * D); w.dy = f(B * D); w.dh = f(B * mx); w.dz = f(B * mx);
+    w.fwd_ws_bytes = ddg_denoiser_workspace_bytes(B, D, E, L);
+    w.fwd_ws = (float *)take(w.fwd_ws_bytes);
+    w.total = o;
+}
+
+extern "C" size_t ddg_train_workspace_bytes(int64_t batch_rows, int in_dim, int enc_dim, int lat_dim, int disc_lat_dim,
+                                            int C) {
+    if (batch_rows < 1 || in_dim < 1 || enc_dim < 1 || lat_dim < 1 || disc_lat_dim < 1 || C < 1) return 0;
+    TrainWs w;
+    train_carve(w, nullptr, batch_rows, in_dim, enc_dim, lat_dim, disc_lat_dim, C);
+    return w.total;
+}
+
+static inline unsigned g256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+static int check_batch(const ddg_train_batch *b) {
+    if (!b || !b->x0 || !b->M || !b->m || !b->t || b->rows < 1 || b->rows > (1 << 20)) return DDG_E_ARG;
+    if (b->drop_p < 0.f || b->drop_p >= 1.f) return DDG_E_ARG;
+    return DDG_OK;
+}
+
+// forward of the denoiser with every activation kept (model/Diffusion.py:179-201, train mode)
+static int gen_forward_saved(const ddg_gen_weights *w, const ddg_train_batch *b, const float *sched, int T,
+                             const int32_t *offsets, const uint8_t *is_cat, int C, float bn_eps, TrainWs &ws,
+                             void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)b->rows, D = w->in_dim, E = w->enc_dim, L = w->lat_dim;
+    int rc = ddg_forward_noise(b->x0, b->eps, b->t, 0, sched, T, b->seed, b->stream_id * 8 + 7, ws.xt,
+                               b->eps ? nullptr : ws.dres /* on-chip eps kept for the x_{t-1} build */, B, D, stream);
+    if (rc) return rc;
+    k_add_emb<<<g256((int64_t)B * D), 256, 0, s>>>(ws.xt, w->temb, b->t, B, D, ws.h0);
+    const size_t mx = (size_t)(E > L ? E : L);
+    if (hipMemsetAsync(ws.st[0], 0, 3 * tal(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
+    const float *Wl[3] = {w->W1, w->W2, w->W3}, *bl[3] = {w->b1, w->b2, w->b3};
+    const float *gl[3] = {w->g1, w->g2, w->g3}, *bel[3] = {w->be1, w->be2, w->be3};
+    const uint8_t *dl[3] = {b->drop0, b->drop1, b->drop2};
+    float *zl[3] = {ws.z1, ws.z2, ws.z3}, *hl[3] = {ws.h1, ws.h2, ws.h3}, *gt[3] = {ws.g1, ws.g2, ws.g3};
+    const int win[3] = {D, E, L}, wout[3] = {E, L, E};
+    const float *hin = ws.h0;
+    for (int l = 0; l < 3; ++l) {
+        rc = ddg_linear(hin, nullptr, win[l], Wl[l], bl[l], DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr,
+                        nullptr, 0.f, 0, 0, zl[l], ws.st[l], B, win[l], wout[l], stream);
+        if (rc) return rc;
+        rc = ddg_bn_finalize(ws.st[l], gl[l], bel[l], (double)B, bn_eps, ws.sc[l], ws.sf[l], wout[l], stream);
+        if (rc) return rc;
+        k_bn_act_fwd<<<g256((int64_t)B * wout[l]), 256, 0, s>>>(zl[l], ws.sc[l], ws.sf[l], dl[l], b->drop_p, b->seed,
+                                                               b->stream_id * 4 + l, B, wout[l], hl[l], gt[l]);
+        hin = hl[l];
+    }
+    rc = ddg_linear(ws.h3, nullptr, E, w->W4, w->b4, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, ws.y, nullptr, B, E, D, stream);
+    if (rc) return rc;
+    rc = ddg_head(ws.y, offsets, is_cat, C, ws.pred, B, D, stream);
+    if (rc) return rc;
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// discriminator forward with saved activations on xtj1 built from `pred`
+static int disc_forward_saved(const ddg_disc_weights *dw, const ddg_train_batch *b, const float *pred,
+                              const float *eps, const float *sched, int T, int D, TrainWs &ws, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int B = (int)b->rows, H = dw->lat_dim, C = dw->out_dim;
+    k_xtj1_train<<<g256((int64_t)B * D), 256, 0, s>>>(pred, ws.xt, b->x0, eps, b->M, b->t, sched, T, B, D, ws.xtj1);
+    int rc = ddg_linear(ws.xtj1, ws.xt, D, dw->W1, dw->b1, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                        0.f, 0, 0, ws.a1, nullptr, B, 2 * D, H, stream);
+    if (rc) return rc;
+    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a1, dw->e1, b->t, B, H, ws.r1);
+    rc = ddg_linear(ws.r1, nullptr, H, dw->W2, dw->b2, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, ws.a2, nullptr, B, H, H, stream);
+    if (rc) return rc;
+    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a2, dw->e2, b->t, B, H, ws.r2);
+    rc = ddg_linear(ws.r2, nullptr, H, dw->W3, dw->b3, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, ws.a3, nullptr, B, H, H, stream);
+    if (rc) return rc;
+    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a3, dw->e3, b->t, B, H, ws.r3);
+    rc = ddg_linear(ws.r3, nullptr, H, dw->W4, dw->b4, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
+                    0, 0, ws.a4, nullptr, B, H, C, stream);
+    if (rc) return rc;
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generator step: loss = w_res * Res + w_gd * G_D, gradients of every generator parameter
+// ---------------------------------------------------------------------------------------------
+extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                                   const float *sched_dev, int T, const int32_t *offsets_dev,
+                                   const uint8_t *is_cat_dev, int C, float w_res, float w_gd, float bn_eps,
+                                   const ddg_gen_grads *grads, float *losses_dev, float *pred_out, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!gw || !dw || !sched_dev || !offsets_dev || !is_cat_dev || !grads || !losses_dev || C < 1 || T < 2)
+        return DDG_E_ARG;
+    const int B = (int)b->rows, D = gw->in_dim, E = gw->enc_dim, L = gw->lat_dim, H = dw->lat_dim;
+    if (dw->in_dim != 2 * D || dw->out_dim != C) return DDG_E_ARG;
+    TrainWs ws;
+    train_carve(ws, (char *)workspace, B, D, E, L, H, C);
+    if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+
+    rc = gen_forward_saved(gw, b, sched_dev, T, offsets_dev, is_cat_dev, C, bn_eps, ws, stream);
+    if (rc) return rc;
+    const float *eps = b->eps ? b->eps : ws.dres;
+    // G_D branch first (it reads the on-chip eps parked in ws.dres), then the reconstruction loss
+    rc = disc_forward_saved(dw, b, ws.pred, eps, sched_dev, T, D, ws, stream);
+    if (rc) return rc;
+    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, 0, w_gd, ws.da4, losses_dev + 1);
+    // input gradient of the discriminator: da4 -> r3 -> a3 -> r2 -> a2 -> r1 -> a1 -> cat(xtj1, x_t)
+    if ((rc = gemm_dA(ws.da4, dw->W4, ws.dA, B, H, C, s))) return rc;
+    k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
+    if ((rc = gemm_dA(ws.dB, dw->W3, ws.dA, B, H, H, s))) return rc;
+    k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r2, B * H, ws.dB);
+    if ((rc = gemm_dA(ws.dB, dw->W2, ws.dA, B, H, H, s))) return rc;
+    k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r1, B * H, ws.dB);
+    if ((rc = gemm_dA(ws.dB, dw->W1, ws.dcat, B, 2 * D, H, s))) return rc;
+
+    k_res_loss_grad<<<1, 256, (size_t)C * 4, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ws.dres,
+                                                  losses_dev);
+    k_head_bwd<<<g256((int64_t)B * C), 256, 0, s>>>(ws.dres, w_res, ws.dcat, 2 * D, b->M, b->t, sched_dev, T, ws.pred,
+                                                   offsets_dev, is_cat_dev, C, B, D, ws.dy);
+    // layer 4
+    if ((rc = gemm_dW(ws.dy, ws.h3, grads->W4, B, E, D, s))) return rc;
+    k_colsum<<<g256(D), 256, 0, s>>>(ws.dy, B, D, grads->b4);
+    if ((rc = gemm_dA(ws.dy, gw->W4, ws.dh, B, E, D, s))) return rc;
+    // layers 3, 2, 1
+    const float *Wl[3] = {gw->W1, gw->W2, gw->W3}, *gl[3] = {gw->g1, gw->g2, gw->g3};
+    float *dWl[3] = {grads->W1, grads->W2, grads->W3}, *dbl[3] = {grads->b1, grads->b2, grads->b3};
+    float *dgl[3] = {grads->g1, grads->g2, grads->g3}, *dbel[3] = {grads->be1, grads->be2, grads->be3};
+    float *zl[3] = {ws.z1, ws.z2, ws.z3}, *gt[3] = {ws.g1, ws.g2, ws.g3};
+    const float *hin[3] = {ws.h0, ws.h1, ws.h2};
+    const int win[3] = {D, E, L}, wout[3] = {E, L, E};
+    for (int l = 2; l >= 0; --l) {
+        k_bn_act_bwd<<<(wout[l] + 63) / 64, 64, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l], ws.dz,
+                                                        dgl[l], dbel[l]);
+        if ((rc = gemm_dW(ws.dz, hin[l], dWl[l], B, win[l], wout[l], s))) return rc;
+        k_colsum<<<g256(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
+        if ((rc = gemm_dA(ws.dz, Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
+    }
+    k_emb_grad<<<g256((int64_t)gw->n_steps * D), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
+    if (pred_out &&
+        hipMemcpyAsync(pred_out, ws.pred, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return DDG_E_LAUNCH;
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// discriminator step: loss = loss_scale * D_loss, gradients of every discriminator parameter
+// ---------------------------------------------------------------------------------------------
+extern "C" int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                                    const float *sched_dev, int T, const int32_t *offsets_dev,
+                                    const uint8_t *is_cat_dev, int C, float loss_scale, float bn_eps,
+                                    const ddg_disc_grads *grads, float *loss_dev, float *pred_out, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    int rc = check_batch(b);
+    if (rc) return rc;
+    if (!gw || !dw || !sched_dev || !offsets_dev || !is_cat_dev || !grads || !loss_dev || C < 1 || T < 2)
+        return DDG_E_ARG;
+    const int B = (int)b->rows, D = gw->in_dim, E = gw->enc_dim, L = gw->lat_dim, H = dw->lat_dim;
+    if (dw->in_dim != 2 * D || dw->out_dim != C) return DDG_E_ARG;
+    TrainWs ws;
+    train_carve(ws, (char *)workspace, B, D, E, L, H, C);
+    if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+
+    // generator forward only (fused inference path, train-mode BN + dropout)
+    rc = ddg_forward_noise(b->x0, b->eps, b->t, 0, sched_dev, T, b->seed, b->stream_id * 8 + 7, ws.xt,
+                           b->eps ? nullptr : ws.dres, B, D, stream);
+    if (rc) return rc;
+    rc = ddg_denoiser_fwd(gw, ws.xt, b->t, 0, b->drop0, b->drop1, b->drop2, b->drop_p, b->seed, b->stream_id, bn_eps,
+                          offsets_dev, is_cat_dev, C, 1, ws.pred, B, ws.fwd_ws, ws.fwd_ws_bytes, stream);
+    if (rc) return rc;
+    const float *eps = b->eps ? b->eps : ws.dres;
+    rc = disc_forward_saved(dw, b, ws.pred, eps, sched_dev, T, D, ws, stream);
+    if (rc) return rc;
+    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, 1, loss_scale, ws.da4, loss_dev);
+    // layer 4
+    if ((rc = gemm_dW(ws.da4, ws.r3, grads->W4, B, H, C, s))) return rc;
+    k_colsum<<<g256(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
+    if ((rc = gemm_dA(ws.da4, dw->W4, ws.dA, B, H, C, s))) return rc;
+    // layer 3
+    k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
+    k_emb_grad<<<g256((int64_t)dw->n_steps * H), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e3);
+    if ((rc = gemm_dW(ws.dB, ws.r2, grads->W3, B, H, H, s))) return rc;
+    k_colsum<<<g256(H), 256, 0, s>>>(ws.dB, B, H, grads->b3);
+    if ((rc = gemm_dA(ws.dB, dw->W3, ws.dA, B, H, H, s))) return rc;
+    // layer 2
+    k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r2, B * H, ws.dB);
+    k_emb_grad<<<g256((int64_t)dw->n_steps * H), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e2);
+    if ((rc = gemm_dW(ws.dB, ws.r1, grads->W2, B, H, H, s))) return rc;
+    k_colsum<<<g256(H), 256, 0, s>>>(ws.dB, B, H, grads->b2);
+    if ((rc = gemm_dA(ws.dB, dw->W2, ws.dA, B, H, H, s))) return rc;
+    // layer 1: input = cat(xtj1, x_t)
+    k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r1, B * H, ws.dB);
+    k_emb_grad<<<g256((int64_t)dw->n_steps * H), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e1);
+    if ((rc = gemm_small(ws.dB, 1, H, ws.xtj1, D, 1, grads->W1, 2 * D, H, D, B, s))) return rc;
+    if ((rc = gemm_small(ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B, s))) return rc;
+    k_colsum<<<g256(H), 256, 0, s>>>(ws.dB, B, H, grads->b1);
+    if (pred_out &&
+        hipMemcpyAsync(pred_out, ws.pred, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return DDG_E_LAUNCH;
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import DiscWeights, GenWeights, check, lib
+from ._lib import DiscGrads, DiscWeights, GenGrads, GenWeights, TrainBatch, check, lib
 
 PRO_NONE, PRO_ADD_EMB, PRO_BN_RELU, PRO_EMB_RELU = 0, 1, 2, 3
 _NAMES8 = ("betas", "alphas", "sqrt_alphas", "one_by_sqrt_alpha_s", "sqrt_beta_s", "alpha_cumulative",
@@ -244,6 +244,87 @@ def disc_fwd(P: DiscParams, xtj1, xt, t, out=None):
     check(lib().ddg_disc_fwd(C.byref(P.c), _ptr(xtj1, torch.float32), _ptr(xt, torch.float32), tp, tu, _ptr(out), rows,
                              ws.data_ptr(), ws.numel(), _stream()), "ddg_disc_fwd")
     return out
+
+
+# --------------------------------------------------------------------------- a11-a15 training step
+GEN_KEYS = ("linears.0.weight", "linears.0.bias", "linears.1.weight", "linears.1.bias",
+            "linears.4.weight", "linears.4.bias", "linears.5.weight", "linears.5.bias",
+            "linears.8.weight", "linears.8.bias", "linears.9.weight", "linears.9.bias",
+            "linears.12.weight", "linears.12.bias", "time_embedding.weight")
+DISC_KEYS = ("linears.0.weight", "linears.0.bias", "linears.2.weight", "linears.2.bias", "linears.4.weight",
+             "linears.4.bias", "linears.6.weight", "linears.6.bias", "step_embeddings.0.weight",
+             "step_embeddings.1.weight", "step_embeddings.2.weight")
+
+
+def _batch_struct(x0, M, m, t, eps, drops, drop_p, seed, stream_id) -> TrainBatch:
+    d = [None, None, None] if drops is None else [_ptr(q, torch.uint8) for q in drops]
+    return TrainBatch(_ptr(x0, torch.float32), _ptr(M, torch.float32), _ptr(m, torch.float32), _ptr(t, torch.int64),
+                      _ptr(eps, torch.float32), d[0], d[1], d[2], float(drop_p), int(seed), int(stream_id),
+                      x0.shape[0])
+
+
+class ParamGrads:
+    """Gradient (and Adam moment) buffers shaped like a GenParams / DiscParams tensor dict."""
+
+    def __init__(self, P, keys):
+        self.keys = keys
+        self.P = P
+        self.g = {k: torch.zeros_like(P.t[k]) for k in keys}
+        self.exp_avg = {k: torch.zeros_like(P.t[k]) for k in keys}
+        self.exp_avg_sq = {k: torch.zeros_like(P.t[k]) for k in keys}
+        self.step = 0
+        n = len(keys)
+        arr = lambda d: (C.c_void_p * n)(*[d[k].data_ptr() for k in keys])
+        self._p, self._g, self._m, self._v = arr(P.t), arr(self.g), arr(self.exp_avg), arr(self.exp_avg_sq)
+        self._n = (C.c_int64 * n)(*[P.t[k].numel() for k in keys])
+
+    def adam_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """torch.optim.Adam.step() on the device tensors of P (model/Diffusion.py:571-573)."""
+        self.step += 1
+        check(lib().ddg_adam_step(len(self.keys), self._p, self._g, self._m, self._v, self._n, self.step, lr,
+                                  betas[0], betas[1], eps, weight_decay, _stream()), "ddg_adam_step")
+
+
+def _train_ws(PG, PD, rows, C_, device):
+    nb = lib().ddg_train_workspace_bytes(rows, PG.in_dim, PG.enc_dim, PG.lat_dim, PD.lat_dim, C_)
+    return _workspace(nb, device, "train")
+
+
+def train_gen_grads(PG: "GenParams", PD: "DiscParams", grads: ParamGrads, x0, M, m, t, layout: FieldLayout,
+                    sched_dev, T: int, w_res: float, w_gd: float, eps=None, drops=None, drop_p: float = 0.2,
+                    seed: int = 0, stream_id: int = 0, bn_eps: float = 1e-5, want_pred: bool = False):
+    """Generator step up to the gradients (train_one_epoch_Generator, model/Diffusion.py:287-310).
+    Returns (losses[2] device tensor = res, g_d; pred or None)."""
+    dev = x0.device
+    off, cat = layout.on(dev)
+    ws = _train_ws(PG, PD, x0.shape[0], layout.C, dev)
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    pred = torch.empty_like(x0) if want_pred else None
+    b = _batch_struct(x0, M, m, t, eps, drops, drop_p, seed, stream_id)
+    gs = GenGrads(*[grads.g[k].data_ptr() for k in GEN_KEYS])
+    check(lib().ddg_train_gen_grads(C.byref(PG.c), C.byref(PD.c), C.byref(b), _ptr(sched_dev, torch.float32), T,
+                                    _ptr(off), _ptr(cat), layout.C, float(w_res), float(w_gd), bn_eps, C.byref(gs),
+                                    _ptr(losses), _ptr(pred), ws.data_ptr(), ws.numel(), _stream()),
+          "ddg_train_gen_grads")
+    return losses, pred
+
+
+def train_disc_grads(PG: "GenParams", PD: "DiscParams", grads: ParamGrads, x0, M, m, t, layout: FieldLayout,
+                     sched_dev, T: int, loss_scale: float = 1.0, eps=None, drops=None, drop_p: float = 0.2,
+                     seed: int = 0, stream_id: int = 0, bn_eps: float = 1e-5, want_pred: bool = False):
+    """Discriminator step up to the gradients (train_one_epoch_discriminator_noise_x, :356-370)."""
+    dev = x0.device
+    off, cat = layout.on(dev)
+    ws = _train_ws(PG, PD, x0.shape[0], layout.C, dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    pred = torch.empty_like(x0) if want_pred else None
+    b = _batch_struct(x0, M, m, t, eps, drops, drop_p, seed, stream_id)
+    gs = DiscGrads(*[grads.g[k].data_ptr() for k in DISC_KEYS])
+    check(lib().ddg_train_disc_grads(C.byref(PG.c), C.byref(PD.c), C.byref(b), _ptr(sched_dev, torch.float32), T,
+                                     _ptr(off), _ptr(cat), layout.C, float(loss_scale), bn_eps, C.byref(gs),
+                                     _ptr(loss), _ptr(pred), ws.data_ptr(), ws.numel(), _stream()),
+          "ddg_train_disc_grads")
+    return loss, pred
 
 
 # --------------------------------------------------------------------------- a1 + a2

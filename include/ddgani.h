@@ -166,6 +166,63 @@ int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const float *xt, 
                  void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a11-a15  one minibatch training step      model/Diffusion.py:245-379, :452-526, :571-573
+ *
+ * The reference's step is: sample_x (128 rows) -> randint t in [2,T] -> forward_diffusion ->
+ * Generator_x0 (train mode) -> losses -> autograd backward -> Adam.  Here the caller gathers the
+ * batch (rows x0/M/m), draws or uploads the randomness, and calls
+ *   ddg_train_gen_grads   loss_G = w_res*res_loss_func + w_gd*G_d_loss_func  (:297-303; the FD and
+ *                         Learner terms are constants under no_grad) and the
+ *                         gradient of every generator parameter (what loss.backward() leaves in
+ *                         .grad after optimizer.zero_grad(), :309-310)
+ *   ddg_train_disc_grads  loss_D = loss_scale*D_loss_func (:364-367, loss_scale = D_weight on
+ *                         epochs divisible by 100, :338) and the gradient of every discriminator
+ *                         parameter (:369-370)
+ *   ddg_adam_step         torch.optim.Adam.step(): lr 1e-4, betas (0.9,0.999), eps 1e-8, coupled
+ *                         weight_decay 1e-4 for the generator / 0 for the discriminator (:571-573)
+ * Gradient structs mirror the weight structs (same tensor shapes).  losses: device floats.
+ * eps / drop0..2 == NULL -> drawn on chip (Philox, seed/stream_id) exactly as ddg_denoiser_fwd does.
+ * pred_out (optional): the generator's prediction [rows,D] of this step.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddg_train_batch {
+    const float *x0;            /* [rows,D] sampled rows of the encoded table (sample_x, utils/util.py:582) */
+    const float *M;             /* [rows,D] expanded mask                                     */
+    const float *m;             /* [rows,C] column mask as float (m_data, model/Diffusion.py:574) */
+    const int64_t *t;           /* [rows] timesteps in [2,T]                                  */
+    const float *eps;           /* [rows,D] forward-diffusion noise or NULL                   */
+    const uint8_t *drop0, *drop1, *drop2;   /* keep masks [rows,enc],[rows,lat],[rows,enc] or NULL */
+    float drop_p;
+    uint64_t seed, stream_id;
+    int64_t rows;
+} ddg_train_batch;
+
+typedef struct ddg_gen_grads {
+    float *W1, *b1, *g1, *be1, *W2, *b2, *g2, *be2, *W3, *b3, *g3, *be3, *W4, *b4, *temb;
+} ddg_gen_grads;
+
+typedef struct ddg_disc_grads {
+    float *W1, *b1, *W2, *b2, *W3, *b3, *W4, *b4, *e1, *e2, *e3;
+} ddg_disc_grads;
+
+size_t ddg_train_workspace_bytes(int64_t batch_rows, int in_dim, int enc_dim, int lat_dim, int disc_lat_dim,
+                                 int C);
+/* losses_dev: float[2] = {res_loss, g_d_loss} (unweighted values) */
+int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                        const float *sched_dev, int T, const int32_t *offsets_dev, const uint8_t *is_cat_dev,
+                        int C, float w_res, float w_gd, float bn_eps, const ddg_gen_grads *grads,
+                        float *losses_dev, float *pred_out, void *workspace, size_t workspace_bytes,
+                        void *stream);
+/* loss_dev: float[1] = D_loss (unscaled value) */
+int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                         const float *sched_dev, int T, const int32_t *offsets_dev, const uint8_t *is_cat_dev,
+                         int C, float loss_scale, float bn_eps, const ddg_disc_grads *grads, float *loss_dev,
+                         float *pred_out, void *workspace, size_t workspace_bytes, void *stream);
+/* host arrays of n_tensors (<= 16) device pointers; step counts from 1 */
+int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
+                  float *const *exp_avg_sq, const int64_t *numel, int step, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * a1 + a2  init_attn_2 core: row-attention top-k fill   utils/util.py:439-496
  *
  * For every local query row j and table column c with mq[j,c]==0:
