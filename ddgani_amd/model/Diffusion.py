@@ -156,3 +156,218 @@ def reverse_diffusion_G_D_sample(generator_x, discriminator_noise_x, DS, timeste
         from .Discriminator_model import sampler_disc_tail
         d_out = sampler_disc_tail(discriminator_noise_x, DS, x, x0_hat, eps2=eps2, seed=seed)
     return x0_hat, d_out
+
+
+# ==========================================================================================
+# training side (model/Diffusion.py:245-379, :551-637)
+# ==========================================================================================
+class HostRandom:
+    """Parity mode: every random draw of the reference's training / sampling loop is made on the
+    host with the SAME generator calls in the SAME order as the reference's CPU run (numpy's global
+    RNG for ``sample_x``, torch's global CPU generator for timesteps, noise and dropout masks:
+    SURVEY.md appendix A.5) and uploaded.  A run seeded like the reference then sees the reference's
+    random stream."""
+    name = "host"
+
+    def batch_indices(self, n_rows, batch):
+        return list(np.random.choice(n_rows, batch, replace=False))          # utils/util.py:583
+
+    def timesteps(self, T, batch, device):
+        return torch.randint(low=2, high=T + 1, size=(batch,)).to(device)    # model/Diffusion.py:292
+
+    def normal(self, rows, dim, device):
+        return torch.randn_like(torch.empty(rows, dim)).to(device)           # model/Diffusion.py:392
+
+    def dropout(self, rows, widths, device):
+        # nn.Dropout(0.2) in train mode on the CPU draws empty_like(h).bernoulli_(0.8) per layer
+        return [torch.empty(rows, w).bernoulli_(0.8).to(torch.uint8).to(device) for w in widths]
+
+    def sampler_T(self, T, rows):
+        torch.randint(low=T, high=T + 1, size=(rows,))                        # model/Diffusion.py:428 (value fixed)
+
+
+class ChipRandom:
+    """Throughput mode: noise and dropout are generated inside the kernels (Philox4x32-10 keyed by
+    (seed, stream)); batch rows are drawn without replacement by a numpy Generator (O(batch))."""
+    name = "chip"
+
+    def __init__(self, seed=0):
+        self.seed = int(seed)
+        self.counter = 0
+        self.gen = np.random.default_rng(seed)
+
+    def next_stream(self):
+        self.counter += 1
+        return self.counter
+
+    def batch_indices(self, n_rows, batch):
+        return self.gen.choice(n_rows, batch, replace=False, shuffle=False).tolist()
+
+    def timesteps(self, T, batch, device):
+        return torch.from_numpy(self.gen.integers(2, T + 1, size=batch)).to(device)
+
+
+def consume_dead_module_rng(input_dim, n_steps):
+    """The reference constructs an eps-MLP (``Diffusion``) and its EMA that are never trained or
+    called (BaseLine/DiffGANI.py:49-51); their default initialisers advance torch's global RNG before
+    the live networks are initialised.  Draw-equivalent throwaway layers keep the streams aligned:
+    four Linear(D,D) and four Embedding(n_steps,D) (model/Diffusion.py:113-132)."""
+    for _ in range(4):
+        nn.Linear(input_dim, input_dim)
+    for _ in range(4):
+        nn.Embedding(n_steps, input_dim)
+
+
+class _NetState:
+    """Device parameters + gradient / Adam buffers of one network (the role of ``optim.Adam``)."""
+
+    def __init__(self, params, keys, lr, weight_decay):
+        self.P = params
+        self.buf = ops.ParamGrads(params, keys)
+        self.lr, self.wd = lr, weight_decay
+
+    def step(self):
+        self.buf.adam_step(lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=self.wd)
+
+
+def _train_batch(rnd, x, M, m_data, T, device, gen_widths):
+    idx = rnd.batch_indices(x.shape[0], 128)                  # batch hard-coded to 128 (model/Diffusion.py:287)
+    it = torch.as_tensor(idx, dtype=torch.long, device=device)
+    x0, Mb, mb = x[it].contiguous(), M[it].contiguous(), m_data[it].contiguous()
+    t = rnd.timesteps(T, x0.shape[0], device)
+    if rnd.name == "host":
+        eps = rnd.normal(x0.shape[0], x0.shape[1], device)
+        drops = rnd.dropout(x0.shape[0], gen_widths, device)
+        return x0, Mb, mb, t, dict(eps=eps, drops=drops)
+    return x0, Mb, mb, t, dict(seed=rnd.seed, stream_id=rnd.next_stream())
+
+
+def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, loss_scaler, other_loss, epoch,
+                              total_epochs, timesteps, device, field, M, m_data, loss_weight, FDs_model_list, fields,
+                              zero_feed_data, rnd=None):
+    """reference: model/Diffusion.py:245-318.  ``timesteps`` minibatch steps of the generator:
+    loss = Res*Res_weight + G_D*G_D_weight (+ the FD / Learner terms, constants under no_grad that do
+    not reach a gradient).  ``optimizer`` is the generator's ``_NetState``; ``loss_scaler`` is unused
+    (the reference's generator step does not use it either, :306-311).  Returns the mean loss."""
+    rnd = rnd or HostRandom()
+    PG, PD = optimizer.P, discriminator_noise_x.device_params()
+    widths = (PG.enc_dim, PG.lat_dim, PG.enc_dim)
+    total = 0.0
+    losses = []
+    for _ in range(timesteps):
+        x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths)
+        l, _ = ops.train_gen_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, model.layout, DS.table, timesteps,
+                                   loss_weight["Res_weight"], loss_weight["G_D_weight"], **kw)
+        optimizer.step()
+        losses.append(l)
+    if losses:
+        ls = torch.stack(losses).double().cpu()
+        total = float((ls[:, 0] * loss_weight["Res_weight"] + ls[:, 1] * loss_weight["G_D_weight"]).mean()) \
+            + float(other_loss)
+    return total
+
+
+def train_one_epoch_discriminator_noise_x(generator_x0, discriminator_noise_x, DS, x, optimizer, loss_scaler,
+                                          other_loss, epoch, total_epochs, timesteps, device, field, M, m_data,
+                                          loss_weight, rnd=None):
+    """reference: model/Diffusion.py:321-379.  ``timesteps`` minibatch steps of the discriminator on
+    D_loss_func (scaled by D_weight on epochs divisible by 100, :338 vs :367)."""
+    rnd = rnd or HostRandom()
+    PG, PD = generator_x0.device_params(), optimizer.P
+    widths = (PG.enc_dim, PG.lat_dim, PG.enc_dim)
+    scale = loss_weight["D_weight"] if epoch % 100 == 0 else 1.0
+    losses = []
+    for _ in range(timesteps):
+        x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths)
+        l, _ = ops.train_disc_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, generator_x0.layout, DS.table, timesteps,
+                                    loss_scale=scale, **kw)
+        optimizer.step()
+        losses.append(l)
+    return float(torch.stack(losses).double().mean().cpu()) * scale if losses else 0.0
+
+
+def host_sampler_randomness(rnd, T, rows, dim, widths, device):
+    """The draws of one reverse_diffusion_G_D_sample call in the reference's order (A.5)."""
+    rnd.sampler_T(T, rows)
+    eps_T = rnd.normal(rows, dim, device)
+    zs, drops = [], []
+    for ts in range(T, 1, -1):
+        if ts > 2:
+            zs.append(rnd.normal(rows, dim, device))
+            drops.append(rnd.dropout(rows, widths, device))
+        else:
+            drops.append(rnd.dropout(rows, widths, device))
+            eps2 = rnd.normal(rows, dim, device)
+    return ExplicitRandomness(eps_T=eps_T, zs=zs, drops=drops), eps2
+
+
+def train_diffusion_discriminator(discriminator, generator_x, discriminator_noise_x, FDs_model_list, num_steps, epochs,
+                                  lr, batch_size, loss_weight, data_m, impute_data_code, label_data, fields, value_cat,
+                                  values, miss_data_x, enc, ori_data, continuous_cols, label_num, device, use_Learner,
+                                  rng="host", sample_every=100, log=None):
+    """reference: model/Diffusion.py:551-637 -> imputed table (``.values`` of the best epoch's decode).
+    ``lr`` and ``batch_size`` are accepted and ignored exactly like the reference (:571-573, :287).
+    rng="host" replays the reference's CPU random streams (parity), rng="chip" draws on the GPU."""
+    from ..utils.util import get_M_by_data_m, get_valid_data_index, reconvert_data, test_impute_data_rmse
+    from .Learner import train_L_code
+    import pandas as pd
+    print("------------------Diffusion Discriminator train--------------------")
+    impute_data = None
+    torch.manual_seed(3047)
+    dev = torch.device(device)
+    generator_x.to(dev)
+    discriminator_noise_x.to(dev)
+    M_tensor = get_M_by_data_m(data_m, fields, dev)
+    x = impute_data_code.to(dev).contiguous()
+    zero_feed_data = M_tensor * x
+    # validation split of the Learner; with rng="host" it runs where the reference's CPU run does, so
+    # that its dropout draws come from the same torch CPU stream (utils/util.py:623-646)
+    vdev = torch.device("cpu") if rng == "host" else dev
+    valid_data_index = get_valid_data_index(data_m, discriminator.to(vdev), impute_data_code.to(vdev), vdev)
+    vset = set(int(i) for i in valid_data_index)
+    train_data_index = [i for i in range(len(data_m)) if i not in vset]
+    label_data_code = torch.FloatTensor(label_data.values).to(dev)
+    vidx = torch.as_tensor(np.asarray(valid_data_index, dtype=np.int64), device=dev)
+    tidx = torch.as_tensor(np.asarray(train_data_index, dtype=np.int64), device=dev)
+    x_valid, y_valid = x[vidx], label_data_code[vidx]
+    optG = _NetState(generator_x.device_params(refresh=True), ops.GEN_KEYS, 1e-4, 1e-4)
+    optD = _NetState(discriminator_noise_x.device_params(refresh=True), ops.DISC_KEYS, 1e-4, 0.0)
+    m_data = torch.tensor(np.asarray(data_m)).float().to(dev)
+    no, dim = x.shape
+    DS = Diffusion_setting(num_steps, dim, dev)
+    rnd = HostRandom() if rng == "host" else ChipRandom(3047)
+    widths = (optG.P.enc_dim, optG.P.lat_dim, optG.P.enc_dim)
+    L_loss = 0
+    r_M, b_e = 9999, 0
+    for epoch in range(1, epochs + 1):
+        other_loss = L_loss * loss_weight["L_weight"]
+        train_one_epoch_Generator(generator_x, discriminator_noise_x, DS, x, optG, None, other_loss, epoch, epochs,
+                                  num_steps, dev, fields, M_tensor, m_data, loss_weight, FDs_model_list, fields,
+                                  zero_feed_data, rnd=rnd)
+        train_one_epoch_discriminator_noise_x(generator_x, discriminator_noise_x, DS, x, optD, None, other_loss, epoch,
+                                              epochs, num_steps, dev, fields, M_tensor, m_data, loss_weight, rnd=rnd)
+        if epoch % sample_every == 0:
+            if rng == "host":
+                rand, eps2 = host_sampler_randomness(rnd, num_steps, no, dim, widths, dev)
+                generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout, randomness=rand,
+                                                sched_host=DS.host)
+            else:
+                generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout,
+                                                seed=rnd.seed + 7919 * epoch, sched_host=DS.host)
+            code = ops.mask_merge(x, M_tensor, generator_data, generator_x.layout)      # :598, :606-615
+            cur_r, cur_m = test_impute_data_rmse(code, fields, value_cat, values, miss_data_x.copy(), data_m, enc,
+                                                 ori_data, continuous_cols)
+            if log is not None:
+                log.append((epoch, float(cur_r), float(cur_m)))
+            if use_Learner == 'True':
+                L_loss, acc = train_L_code(1000, code[tidx], label_data_code[tidx], x_valid, y_valid, label_num, dev)
+                L_loss = float(L_loss)
+            else:
+                L_loss = 0
+            if cur_r < r_M:
+                impute_data = pd.DataFrame(reconvert_data(code, fields, value_cat, values, miss_data_x.copy(), data_m,
+                                                          enc))
+                impute_data.columns = values
+                b_e, r_M = epoch, cur_r
+    print(b_e)
+    return impute_data.values

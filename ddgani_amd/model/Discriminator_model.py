@@ -11,6 +11,30 @@ from .. import ops
 from ..ops import DiscParams
 
 
+class D(nn.Module):
+    """Plain discriminator of the reference (model/Discriminator_model.py:5-39): three Linear layers
+    (input->input->input->out) with ReLU + Dropout(0.2) and a sigmoid; the two BatchNorm members are
+    constructed (state_dict parity) but unused, as in the reference.  On the DDGANI path it is only
+    constructed for its RNG draws (BaseLine/DiffGANI.py:52) and trained inside
+    ``get_valid_data_index`` (utils/util.py:625-643) when fewer than 20 % of the rows are complete:
+    a host-preparation step, kept in stock torch ops (SURVEY.md 8(f) "next")."""
+
+    def __init__(self, input_dim, latent_dim, out_dim):
+        super().__init__()
+        self.input_dim, self.latent_dim, self.out_dim = input_dim, latent_dim, out_dim
+        self.fc1 = nn.Linear(input_dim, input_dim)
+        self.fc2 = nn.Linear(input_dim, input_dim)
+        self.fc3 = nn.Linear(input_dim, out_dim)
+        self.batch_normal1 = nn.BatchNorm1d(latent_dim)
+        self.batch_normal2 = nn.BatchNorm1d(out_dim)
+        self.dropout = nn.Dropout(0.2)
+
+    def forward(self, new_x):
+        out = self.dropout(torch.relu(self.fc1(new_x)))
+        out = self.dropout(torch.relu(self.fc2(out)))
+        return torch.sigmoid(self.fc3(out))
+
+
 class Discriminator_noise_x(nn.Module):
     """Parameter container, reference layout (model/Discriminator_model.py:82-102); forward =
     cat -> 3x[Linear, + step_embedding[t], ReLU] -> Linear -> sigmoid (:105-115) on the GPU."""

@@ -1,0 +1,298 @@
+"""Host-side mirror of the reference's ``utils/util.py`` for the imputation path: same function
+names, arguments, return values and side effects (file:line of the reference function in every
+docstring), re-written vectorised so that the data preparation scales to the synthetic tables of
+BASELINE.json, with the N x N row attention handed to the HIP library (``ddg_attn_topk_fill``).
+
+The encoders the reference takes from scikit-learn (``OrdinalEncoder``) and the pandas routines
+whose tie-breaking defines results (``value_counts``) are called as the reference calls them.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .field import CategoricalField, NumericalField
+
+
+# ------------------------------------------------------------------------------------------ metrics
+def normalization(data, parameters=None):
+    """reference: utils/util.py:17-48.  Column-wise (x - min) / (max + 1e-6), max taken after the
+    shift; with ``parameters`` the given min / max are applied."""
+    data = np.asarray(data, dtype=float)
+    if parameters is None:
+        min_val = np.nanmin(data, axis=0)
+        shifted = data - min_val
+        max_val = np.nanmax(shifted, axis=0)
+        norm = shifted / (max_val + 1e-6)
+        parameters = {"min_val": min_val, "max_val": max_val}
+    else:
+        norm = (data - parameters["min_val"]) / (parameters["max_val"] + 1e-6)
+    return norm, parameters
+
+
+def errorLoss(imputed_data, ori_data, M, value_cat, continuous_cols, enc):
+    """reference: utils/util.py:83-139 -> (ARMSE, AMAE).  Categoricals are ordinal-encoded with
+    ``enc``, every column is min-max(+1e-6) normalised by the ground truth, numeric columns score
+    RMSE / MAE over their missing cells, categorical columns the mismatch rate (under both
+    metrics); the mean runs over the columns that have at least one missing cell."""
+    imp = imputed_data.copy()
+    ori = ori_data.copy()
+    if len(value_cat) != 0:
+        imp[value_cat] = enc.transform(imp[value_cat])
+        ori[value_cat] = enc.transform(ori[value_cat])
+    imp = np.nan_to_num(imp.values.astype(float))
+    ori = np.nan_to_num(ori.values.astype(float))
+    ori, par = normalization(ori)
+    imp, _ = normalization(imp, par)
+    miss = 1.0 - np.asarray(M, dtype=float)
+    n_miss = miss.sum(axis=0)
+    is_num = np.zeros(ori.shape[1], dtype=bool)
+    is_num[list(continuous_cols)] = True
+    armse = amae = 0.0
+    used = 0
+    for i in range(ori.shape[1]):
+        if n_miss[i] == 0:
+            continue
+        d = ori[:, i] - imp[:, i]
+        if is_num[i]:
+            armse += np.sqrt(np.sum(miss[:, i] * d ** 2) / n_miss[i])
+            amae += np.sum(miss[:, i] * np.abs(d)) / n_miss[i]
+        else:
+            r = np.sum(miss[:, i] * (ori[:, i] != imp[:, i]).astype("int")) / n_miss[i]
+            armse += r
+            amae += r
+        used += 1
+    return armse / used, amae / used
+
+
+# ------------------------------------------------------------------------------------------ encoding
+def categorical_to_code(miss_data_x, value_cat, enc):
+    """reference: utils/util.py:538-550.  Ordinal-encodes the categorical columns IN PLACE (callers
+    pass a copy) and returns (frame, encoder); fits a new OrdinalEncoder when ``enc`` is None."""
+    if len(value_cat) == 0:
+        return miss_data_x, None
+    if enc is None:
+        from sklearn.preprocessing import OrdinalEncoder
+        enc = OrdinalEncoder()
+        enc.fit(miss_data_x[value_cat])
+    miss_data_x[value_cat] = enc.transform(miss_data_x[value_cat])
+    return pd.DataFrame(miss_data_x), enc
+
+
+def Data_convert(data, model_name, continuous_cols):
+    """reference: utils/util.py:52-78 -> (fields, feed_data).  ``data`` has integer column labels;
+    numeric columns become one encoded column, categorical columns a one-hot block; feed_data is a
+    float64 frame [N, D] with columns 0..D-1."""
+    fields = []
+    blocks = []
+    cont = set(continuous_cols)
+    for i, _ in enumerate(list(data)):
+        col = np.asarray(data[i])
+        if i in cont:
+            f = NumericalField(model=model_name)
+            f.get_data(data[i])
+            f.learn()
+            blocks.append(np.asarray(f.convert(col), dtype=float).reshape(-1, 1))
+        else:
+            f = CategoricalField("one-hot", noise=None)
+            f.get_data(data[i])
+            f.learn()
+            blocks.append(f.convert(col).astype(float))
+        fields.append(f)
+    feed = np.concatenate(blocks, axis=1) if blocks else np.zeros((len(data), 0))
+    return fields, pd.DataFrame(feed)
+
+
+def field_widths(fields):
+    return [int(f.dim()) for f in fields]
+
+
+def get_M_by_data_m(data_m, filed, device):
+    """reference: utils/util.py:369-383: the [N,C] mask with every column repeated over the encoded
+    width of its field, as a float tensor on ``device``."""
+    M = np.repeat(np.asarray(data_m), field_widths(filed), axis=1)
+    return torch.tensor(M, dtype=torch.float).to(device)
+
+
+def reconvert_data(x_, fields, value_cat, values, miss_data_x, data_m, enc):
+    """reference: utils/util.py:228-254.  Decode an encoded table (numeric: inverse scaling;
+    categorical: arg-max of the block), then keep the observed cells of ``miss_data_x`` and take
+    only the missing ones from the decoded table; categorical columns come back as their original
+    labels.  Like the reference it ordinal-encodes ``miss_data_x[value_cat]`` in place."""
+    x_np = x_.detach().cpu().numpy() if isinstance(x_, torch.Tensor) else np.asarray(x_)
+    cols = []
+    a = 0
+    for f in fields:
+        d = f.dim()
+        cols.append(np.asarray(f.reverse(x_np[:, a:a + d])).reshape(-1))
+        a += d
+    current = np.stack(cols, axis=1) if cols else np.zeros((x_np.shape[0], 0))
+    if value_cat:
+        miss_data_x[value_cat] = enc.transform(miss_data_x[value_cat])
+    m = np.asarray(data_m)
+    merged = pd.DataFrame(miss_data_x.values * m + current * (1 - m))
+    if value_cat:
+        merged.columns = values
+        merged[value_cat] = enc.inverse_transform(merged[value_cat])
+    return merged
+
+
+def test_impute_data_rmse(x_code, fields, value_cat, values, miss_data_x, data_m, enc, ori_data, continuous_cols):
+    """reference: utils/util.py:648-658 -> (ARMSE, AMAE) of an encoded table."""
+    impute_data = pd.DataFrame(reconvert_data(x_code, fields, value_cat, values, miss_data_x, data_m, enc))
+    impute_data.columns = values
+    return errorLoss(impute_data, ori_data, data_m, value_cat, continuous_cols, enc)
+
+
+def sort_corr(corr_map):
+    """reference: utils/util.py:692-697: per column, the other columns by descending weight
+    (stable, like ``sorted(..., reverse=True)``)."""
+    out = {}
+    for index, row in enumerate(np.asarray(corr_map)):
+        out[index] = sorted(range(len(row)), key=lambda x: row[x], reverse=True)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ attention fill
+def attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat):
+    """Host preparation of init_attn_2 (utils/util.py:390-448): mode-fill 'Null' categoricals,
+    ordinal-encode, z-score / one-hot encode ("mean_std"), expand mask and column weights.
+    Returns (fields, X [N,D] fp32, M [N,D] fp32, W [C,D] fp32, offsets)."""
+    code = miss_data.copy()
+    names = list(miss_data.columns)
+    con_cols = [i for i in range(len(names)) if i not in categorical_cols]
+    for i in categorical_cols:
+        col = names[i]
+        for val in miss_data[col].value_counts().index.tolist():
+            if val != "Null":
+                code[col] = code[col].where(code[col] != "Null", val)
+                break
+    code, enc = categorical_to_code(code, value_cat, enc)
+    code.columns = list(range(code.shape[1]))
+    fields, enc_code = Data_convert(code, "mean_std", con_cols)
+    widths = field_widths(fields)
+    X = torch.tensor(enc_code.values, dtype=torch.float)
+    M = torch.tensor(np.repeat(np.asarray(data_m), widths, axis=1), dtype=torch.float)
+    W = torch.tensor(np.repeat(np.asarray(corr_map), widths, axis=1), dtype=torch.float)
+    return fields, X, M, W, widths
+
+
+def topk_count(n_rows: int, top_k) -> int:
+    """k of the reference (utils/util.py:459): ``int(N * top_k)`` for a fraction; a value >= 1 is an
+    absolute count (extension needed by BASELINE.json config 3, "top_k=10")."""
+    return int(top_k) if top_k >= 1 else int(n_rows * top_k)
+
+
+def init_attn_2(corr_map, miss_data, data_m, categorical_cols, enc, value_cat, device, top_k):
+    """reference: utils/util.py:386-501 -> (DataFrame [N,C] in the original domain, code tensor
+    [N,D] on ``device``).  The C dense N x N softmax / top-k matrices of the reference
+    (:449-466, :484-496) are replaced by one call of the streaming HIP kernel."""
+    if corr_map is None:
+        raise NotImplementedError("init_attn_2(corr_map=None): the unweighted variant (utils/util.py:467-476) is "
+                                  "not on the DDGANI path (BaseLine/DiffGANI.py:21 always passes a map)")
+    from .. import ops
+    values = miss_data.columns
+    fields, X, M, W, widths = attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat)
+    k = topk_count(X.shape[0], top_k)
+    if k < 1:
+        raise IndexError("init_attn_2: int(N * top_k) == 0 (the reference fails at values[-1] here)")
+    dev = torch.device(device)
+    lay = ops.FieldLayout(widths, dev)
+    X0 = (X * M).to(dev)
+    m8 = torch.tensor(np.asarray(data_m) != 0, dtype=torch.uint8).to(dev)
+    new_code = ops.attn_topk_fill(X0, m8, X0, m8, W.to(dev), lay, k)
+    impute_data = pd.DataFrame(reconvert_data(new_code, fields, value_cat, values, miss_data, data_m, enc))
+    impute_data.columns = values
+    return impute_data, new_code
+
+
+# ------------------------------------------------------------------------------------------ training helpers
+def sample_x(x, batch_size):
+    """reference: utils/util.py:582-585: ``batch_size`` distinct rows drawn with numpy's global RNG."""
+    rows = list(np.random.choice(x.size()[0], batch_size, replace=False))
+    return x[rows, :], rows
+
+
+def get_valid_data_index(data_m, discriminator, impute_data_code, device):
+    """reference: utils/util.py:623-646.  20 % of the rows for the Learner's validation split:
+    sampled (python ``random``) from the complete rows when there are enough of them, otherwise the
+    complete rows plus the rows a freshly trained plain discriminator ``D`` scores lowest."""
+    data_m = np.asarray(data_m)
+    n = data_m.shape[0]
+    valid = np.nonzero(np.all(data_m == 1, axis=1))[0].tolist()
+    want = int(0.2 * n)
+    if len(valid) >= want:
+        return random.sample(valid, want)
+    from ..model.Discriminator_model import D
+    from torch import optim
+    cur = D(discriminator.input_dim, discriminator.latent_dim, discriminator.out_dim).to(device)
+    opt = optim.Adam(cur.parameters(), lr=0.002)
+    cur.train()
+    m = torch.tensor(data_m).float().to(device)
+    x = impute_data_code.to(device)
+    for _ in range(1000):
+        opt.zero_grad()
+        p = cur(x)
+        loss = -torch.mean(m * torch.log(p + 1e-8) + (1 - m) * torch.log(1 - p + 1e-8))
+        loss.backward()
+        opt.step()
+    p = cur(x)
+    _, order = torch.sort(p.sum(dim=1))
+    return np.union1d(valid, order[:want].cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------ missingness
+def MAR(data, continuous_cols, miss_seed):
+    """reference: utils/util.py:701-729.  Rows sorted by one random numeric column; a random
+    contiguous run of 40 % of them loses each other cell with probability 0.5."""
+    np.random.seed(miss_seed)
+    n, dim = data.shape
+    pick = np.random.choice(continuous_cols)
+    order = np.argsort(data.iloc[:, pick].values)
+    count = int(n * 0.4)
+    start = np.random.randint(0, n - count + 1)
+    drop = np.random.choice([True, False], size=(count, dim), p=[0.5, 0.5])
+    drop[:, pick] = False
+    data_m = (~pd.isna(data).values).astype(float)
+    rows = order[start:start + count]
+    sub = data_m[rows]
+    sub[drop] = 0
+    data_m[rows] = sub
+    return data_m
+
+
+def MNAR(data, continuous_cols, categorical_cols, miss_seed):
+    """reference: utils/util.py:732-762.  Categorical columns lose cells with probability 0.2;
+    numeric columns lose 40 % of the cells at or below the median."""
+    np.random.seed(miss_seed)
+    n, dim = data.shape
+    data_m = np.ones((n, dim))
+    for i in range(dim):
+        if i in categorical_cols:
+            mask = np.random.choice([True, False], size=n, p=[0.2, 0.8])
+            data_m[mask, i] = 0
+        else:
+            col = data.iloc[:, i].values
+            low = np.where(col <= np.median(col))[0]
+            chosen = np.random.choice(low, int(len(low) * 0.4), replace=False)
+            data_m[chosen, i] = 0
+    return data_m
+
+
+def Region(data, miss_seed):
+    """reference: utils/util.py:766-786.  One rectangle holding 20 % of the cells."""
+    np.random.seed(miss_seed)
+    n, dim = data.shape
+    missing = int(n * dim * 0.2)
+    rows, cols = missing, 1
+    while rows > n:
+        rows //= 2
+        cols = missing // rows
+    r0 = np.random.randint(0, n - rows + 1)
+    c0 = np.random.randint(0, dim - cols + 1)
+    data_m = np.ones((n, dim))
+    data_m[r0:r0 + rows, c0:c0 + cols] = 0
+    return data_m
