@@ -17,7 +17,7 @@ from ..utils.util import Data_convert, categorical_to_code, get_M_by_data_m, ini
 
 
 def get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, categorical_cols, continuous_cols, value_cat,
-                      device, param, label_data, values, ori_data, label_num, args, rng="host", log=None):
+                      device, param, label_data, values, ori_data, label_num, args, rng="host", log=None, epoch_hook=None):
     """reference: BaseLine/DiffGANI.py:14-60 -> np.ndarray [N,C] (object dtype with categoricals).
     Mutates ``nan_data`` in place (mean / mode pre-fill) and round-trips the attention-filled table
     through ``Attention_Input_miss_data_<rate>.csv`` like the reference (:23-24)."""
@@ -57,4 +57,4 @@ def get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, categor
                                                    param["loss_weight"], data_m, impute_data_code, label_data, fields,
                                                    value_cat, values, attention_impute_data, enc, ori_data,
                                                    continuous_cols, label_num, device, args.UseLearner, rng=rng,
-                                                   log=log)
+                                                   log=log, epoch_hook=epoch_hook)

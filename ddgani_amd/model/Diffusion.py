@@ -304,7 +304,7 @@ def host_sampler_randomness(rnd, T, rows, dim, widths, device):
 def train_diffusion_discriminator(discriminator, generator_x, discriminator_noise_x, FDs_model_list, num_steps, epochs,
                                   lr, batch_size, loss_weight, data_m, impute_data_code, label_data, fields, value_cat,
                                   values, miss_data_x, enc, ori_data, continuous_cols, label_num, device, use_Learner,
-                                  rng="host", sample_every=100, log=None):
+                                  rng="host", sample_every=100, log=None, epoch_hook=None):
     """reference: model/Diffusion.py:551-637 -> imputed table (``.values`` of the best epoch's decode).
     ``lr`` and ``batch_size`` are accepted and ignored exactly like the reference (:571-573, :287).
     rng="host" replays the reference's CPU random streams (parity), rng="chip" draws on the GPU."""
@@ -346,6 +346,8 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
                                   zero_feed_data, rnd=rnd)
         train_one_epoch_discriminator_noise_x(generator_x, discriminator_noise_x, DS, x, optD, None, other_loss, epoch,
                                               epochs, num_steps, dev, fields, M_tensor, m_data, loss_weight, rnd=rnd)
+        if epoch_hook is not None:
+            epoch_hook(epoch, generator_x, discriminator_noise_x, valid_data_index)
         if epoch % sample_every == 0:
             if rng == "host":
                 rand, eps2 = host_sampler_randomness(rnd, num_steps, no, dim, widths, dev)

@@ -66,6 +66,26 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
         log.append((float(r[0]), float(r[1])))
         return r
     ref_diff.test_impute_data_rmse = spy
+    # weights after selected epochs (trajectory pins): spy on the discriminator epoch, the last call of an epoch
+    snaps = {}
+    orig_d = ref_diff.train_one_epoch_discriminator_noise_x
+
+    def spy_d(generator_x0, discriminator_noise_x, *a, **k):
+        r = orig_d(generator_x0, discriminator_noise_x, *a, **k)
+        epoch = a[5]
+        if epoch in (1, 2, 10, 100):
+            snaps[f"G_b4_ep{epoch}"] = generator_x0.linears[12].bias.detach().numpy().copy()
+            snaps[f"G_temb_ep{epoch}"] = generator_x0.time_embedding.weight.detach().numpy().copy()
+            snaps[f"D_b6_ep{epoch}"] = discriminator_noise_x.linears[6].bias.detach().numpy().copy()
+        return r
+    ref_diff.train_one_epoch_discriminator_noise_x = spy_d
+    orig_v = ref_diff.get_valid_data_index
+
+    def spy_v(*a, **k):
+        r = orig_v(*a, **k)
+        snaps["valid_index"] = np.asarray(r, dtype=np.int64)
+        return r
+    ref_diff.get_valid_data_index = spy_v
 
     np.random.seed(0); random.seed(0); torch.manual_seed(0)
     (ori_data, miss_data, data_m, label_data, true_data, true_label, continuous_cols, nan_data, test_data,
@@ -95,7 +115,7 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
                         attn_coded=coded(attn), ori_coded=coded(ori_data), epochs=np.array(epochs),
                         categorical_cols=np.array(param["categorical_cols"], dtype=np.int64), T=np.array(param["T"]),
                         top_k=np.array(param["top_k"]), miss_rate=np.array(miss_rate), seed=np.array(seed),
-                        param_json=np.array(json.dumps(param)))
+                        param_json=np.array(json.dumps(param)), **snaps)
     shutil.rmtree(work)
 
 
