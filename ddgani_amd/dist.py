@@ -31,9 +31,13 @@ class Comm:
             out = torch.empty((sum(counts),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
             return out
-        parts = [torch.empty((c,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for c in counts]
-        dist.all_gather(parts, t.contiguous(), group=self.group)
-        return torch.cat(parts, 0)
+        # uneven shards: collectives need equal sizes, so pad every shard to the largest one
+        cmax = max(counts)
+        pad = torch.zeros((cmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        out = torch.empty((cmax * len(counts),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return torch.cat([out[r * cmax:r * cmax + c] for r, c in enumerate(counts)], 0)
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.on:
