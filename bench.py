@@ -85,6 +85,23 @@ def cpu_baseline(tab_cfg, lay_widths, k_frac_rows, T, D, N_full, sample_rows):
                       f"({t_samp:.1f} s = {Nsamp / t_samp:.0f} rows/s); torch CPU fp32, {cores} threads"}
 
 
+def pmc_traffic(workload, rows, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_traffic_<workload>_rows<N>.json: FETCH_SIZE and WRITE_SIZE collected in separate
+    runs of this same command and corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read
+    from inside a timed run, so the figure is attached only when workload and row count match."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{workload}_rows{rows}.json")))[::-1]:
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.startswith(kernel_prefix) and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
+                return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,6 +194,7 @@ def main():
         n_launch = 1 if k <= 32 else 5                      # radix select = 5 launches of the same kernel
         flops = 2.0 * lay.D * pairs_local
         achieved = flops / (sel / n_launch * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(a.workload, N, "void k_attn<24, 0, 16>") if world == 1 else (None, None)
         res = {
             "metric": "imputed rows/sec (T-step reverse diffusion + top_k attn fill)",
             "value": N / (dt / a.steps), "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -189,7 +207,7 @@ def main():
                           "fill": sum(fill_ms) / len(fill_ms), "sampler+merge": sum(samp_ms) / len(samp_ms)},
             "roofline": {"bound": "mfma", "kernel": "k_attn<MODE_TOPK> (similarity + k-th logit selection)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "launch_ms": sel / n_launch},
         }
         if not a.no_cpu and world == 1:
