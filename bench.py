@@ -24,6 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA", dense
 
 
 def parse():
@@ -33,6 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--rows", type=int, default=0, help="override the workload's row count (0 = as named)")
+    ap.add_argument("--attn-mode", default="bf16filter", choices=["f32", "bf16filter"],
+                    help="similarity arithmetic of the attention fill (include/ddgani.h: DDG_ATTN_*)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="sample rows for the CPU attention-fill timing")
     return ap.parse_args()
@@ -137,6 +140,7 @@ def main():
     out_code = torch.empty_like(Xq)
     merged = torch.empty_like(xd)
     sched_host = ops.schedule(T)
+    amode = ops.ATTN_BF16_FILTER if (a.attn_mode == "bf16filter" and k <= 31) else ops.ATTN_F32
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     sel_ms, fill_ms, prep_ms, samp_ms = [], [], [], []
@@ -148,9 +152,9 @@ def main():
             counts = [b - a_ for a_, b in ddist.shard_bounds(N, comm.world)]
             Xk = comm.all_gather_rows(Xq, counts)
             mk = comm.all_gather_rows(mq, counts)
-            plan = ops.AttnPlan(Xq, mq, Xk, mk, tab.W, lay, k, q_row_offset=lo)
+            plan = ops.AttnPlan(Xq, mq, Xk, mk, tab.W, lay, k, q_row_offset=lo, mode=amode)
         else:
-            plan = ops.AttnPlan(Xq, mq, Xq, mq, tab.W, lay, k)
+            plan = ops.AttnPlan(Xq, mq, Xq, mq, tab.W, lay, k, mode=amode)
         plan.prepare()
         e[1].record()
         plan.select(out=out_code)
@@ -194,20 +198,25 @@ def main():
         n_launch = 1 if k <= 32 else 5                      # radix select = 5 launches of the same kernel
         flops = 2.0 * lay.D * pairs_local
         achieved = flops / (sel / n_launch * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(a.workload, N, "void k_attn<24, 0, 16>") if world == 1 else (None, None)
+        filt = amode == ops.ATTN_BF16_FILTER
+        kname = "void k_attn_filt<" if filt else "void k_attn<"
+        peak = PEAK_BF16_MFMA_TFLOPS if filt else PEAK_F32_MFMA_TFLOPS
+        traffic, traffic_src = pmc_traffic(a.workload, N, kname) if world == 1 else (None, None)
         res = {
             "metric": "imputed rows/sec (T-step reverse diffusion + top_k attn fill)",
             "value": N / (dt / a.steps), "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (bf16 MFMA screening, exact fp32 re-scoring of every candidate)" if filt else "f32",
+            "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl['desc']}" + (f" [rows overridden to {N}]" if a.rows else ""),
                        "rows": N, "cols": lay.C, "encoded_dim": lay.D, "top_k": k, "T": T,
                        "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU"},
             "phases_ms": {"prepare(+allgather)": sum(prep_ms) / len(prep_ms), "select": sel,
                           "fill": sum(fill_ms) / len(fill_ms), "sampler+merge": sum(samp_ms) / len(samp_ms)},
-            "roofline": {"bound": "mfma", "kernel": "k_attn<MODE_TOPK> (similarity + k-th logit selection)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma",
+                         "kernel": ("k_attn_filt (bf16 MFMA similarity screening + exact top-k + fill)" if filt else
+                                    "k_attn<MODE_TOPK> (fp32 MFMA similarity + top-k + fill)"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "launch_ms": sel / n_launch},
         }
         if not a.no_cpu and world == 1:

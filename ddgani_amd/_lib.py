@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libddgani_hip.so")
+LIB_PATH = os.environ.get("DDGANI_LIB") or os.path.join(_HERE, "libddgani_hip.so")   # DDGANI_LIB: kernel experiments
 
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_u8p = C.c_void_p
@@ -83,13 +83,14 @@ SIGNATURES = {
                                 C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "ddg_attn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64]),
     "ddg_attn_topk_fill": (C.c_int, [c_f32p, c_u8p, C.c_int64, c_f32p, c_u8p, c_f32p, C.POINTER(C.c_int32),
-                                     C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, c_f32p, c_f32p, c_i32p,
-                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+                                     C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, c_f32p, c_f32p,
+                                     c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddg_attn_prepare": (C.c_int, [c_f32p, c_u8p, C.c_int64, c_f32p, c_u8p, c_f32p, C.POINTER(C.c_int32), C.c_int64,
-                                   C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "ddg_attn_select": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, c_f32p,
+                                   C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
+    "ddg_attn_select": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, c_f32p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
-    "ddg_attn_fill": (C.c_int, [C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64,
+    "ddg_attn_fill": (C.c_int, [C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int,
                                 C.c_int, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

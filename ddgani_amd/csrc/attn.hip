@@ -25,6 +25,7 @@
 // gives a 32 keys x 32 queries logit tile: lane l holds query (l&31), key rows
 // (g&3)+8(g>>2)+4(l>>5), g = 0..15.  The k order is permuted identically for both operands.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 #define QPB 128          // queries per block
@@ -36,6 +37,12 @@ enum { MODE_TOPK = 0, MODE_HIST = 1, MODE_FILL = 2 };
 
 struct AttnArgs {
     const float *Xkp, *Xqp, *Wp;
+    const __bf16 *Xkh;         // [Nk][DP] bf16(Xkp) (filter kernel)
+    const float *kmax;         // [1] largest key 2-norm (filter kernel)
+    float *st_val;             // filter kernel: top-(k+1) lists parked between key-chunk launches,
+    int32_t *st_pos;           //   [block - blk_lo][k+1][512 threads]
+    int key_lo, key_hi;        // key-list positions [key_lo, key_hi) streamed by this launch
+    int blk_lo;                // first workgroup of this launch's group
     const int32_t *klist;      // [C][Nk]
     const int32_t *nk;         // [C]
     const int32_t *qlist;      // [QB*128]
@@ -79,6 +86,62 @@ __device__ __forceinline__ void list_insert_kv(float (&lst)[KCAP], int (&pos)[KC
         pos[i] = gt ? q : lq;
         v = gt ? lv : v;
         q = gt ? lq : q;
+    }
+}
+
+__device__ __forceinline__ int block_column(const int32_t *qb_start, int C, int b) {
+    int lo = 0, hi = C;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (qb_start[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Epilogue shared by the selection kernels: merge the two half-wave lists of each query, then
+// (lanes h == 0) flag a tie at the k-th logit, or softmax over the kept k entries and gather their
+// column-c values: the fill without a second similarity pass (utils/util.py:463-496).
+template <int KCAP>
+__device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP], int64_t slot,
+                                            int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h) {
+    const int ndummy = KCAP - (p.k + 1);
+    float ov[KCAP];
+    int op[KCAP];
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        ov[i] = __shfl_xor(lst[i], 32);
+        op[i] = __shfl_xor(lpos[i], 32);
+    }
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) list_insert_kv<KCAP>(lst, lpos, (i >= ndummy) ? ov[i] : -INFINITY, op[i]);
+    if (h == 0 && qrow >= 0) {
+        const bool tie = nk > p.k && lst[KCAP - 1] == lst[KCAP - 2];
+        p.tau[slot] = (nk >= p.k) ? lst[KCAP - 2] : -INFINITY;
+        float vmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < KCAP - 1; ++i)
+            if (i >= ndummy) vmax = fmaxf(vmax, lst[i]);
+        p.smax[slot] = vmax;
+        p.flag[slot] = tie ? 1 : 0;
+        if (!tie) {
+            float wgt[KCAP];
+            float Zs = 0.f;
+#pragma unroll
+            for (int i = 0; i < KCAP - 1; ++i) {
+                const bool kept = i >= ndummy && lpos[i] >= 0;
+                wgt[i] = kept ? expf(lst[i] - vmax) : 0.f;
+                Zs += wgt[i];
+                lpos[i] = kept ? kl[lpos[i]] : -1;      // key position -> key row
+            }
+            float *dst = p.out_code + (int64_t)qrow * p.D + off_c;
+            for (int e = 0; e < d_c; ++e) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < KCAP - 1; ++i)
+                    if (lpos[i] >= 0) a += wgt[i] * p.Xkp[(int64_t)lpos[i] * DP + off_c + e];
+                dst[e] = (Zs > 0.f) ? a / Zs : 0.f;
+            }
+        }
     }
 }
 
@@ -263,47 +326,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
 
     // ---- per-mode finish
     if constexpr (MODE == MODE_TOPK) {
-        // merge the two half-wave lists of each query, then (lanes h == 0) softmax over the kept k
-        // entries and gather their column-c values: the fill without a second similarity pass
-        const int ndummy = KCAP - (p.k + 1);
-        float ov[KCAP];
-        int op[KCAP];
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            ov[i] = __shfl_xor(lst[i], 32);
-            op[i] = __shfl_xor(lpos[i], 32);
-        }
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) list_insert_kv<KCAP>(lst, lpos, (i >= ndummy) ? ov[i] : -INFINITY, op[i]);
-        if (h == 0 && qrow >= 0) {
-            const bool tie = nk > p.k && lst[KCAP - 1] == lst[KCAP - 2];
-            p.tau[slot] = (nk >= p.k) ? lst[KCAP - 2] : -INFINITY;
-            float vmax = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < KCAP - 1; ++i)
-                if (i >= ndummy) vmax = fmaxf(vmax, lst[i]);
-            p.smax[slot] = vmax;
-            p.flag[slot] = tie ? 1 : 0;
-            if (!tie) {
-                float wgt[KCAP];
-                float Zs = 0.f;
-#pragma unroll
-                for (int i = 0; i < KCAP - 1; ++i) {
-                    const bool kept = i >= ndummy && lpos[i] >= 0;
-                    wgt[i] = kept ? expf(lst[i] - vmax) : 0.f;
-                    Zs += wgt[i];
-                    lpos[i] = kept ? kl[lpos[i]] : -1;      // key position -> key row
-                }
-                float *dst = p.out_code + (int64_t)qrow * p.D + off_c;
-                for (int e = 0; e < d_c; ++e) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int i = 0; i < KCAP - 1; ++i)
-                        if (lpos[i] >= 0) a += wgt[i] * p.Xkp[(int64_t)lpos[i] * DP + off_c + e];
-                    dst[e] = (Zs > 0.f) ? a / Zs : 0.f;
-                }
-            }
-        }
+        topk_finish<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
     } else if (MODE == MODE_HIST) {
         smax = fmaxf(smax, __shfl_xor(smax, 32));
         if (p.level == 0 && h == 0) p.smax[slot] = smax;
@@ -349,6 +372,228 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             if (p.out_nvalid) p.out_nvalid[(int64_t)qrow * p.C + c] = nk;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 screening kernel (DDG_ATTN_BF16_FILTER, k <= DDG_MAX_TOPK_REG).
+//
+// The logits of one (query, column) pair are first computed from the bf16 roundings of both operands
+// on the bf16 MFMA (v_mfma_f32_32x32x16_bf16: 16x the fp32-matrix rate, half the key bytes).  For
+// q = W[c]*x_j and key k:  | sum_d bf16(q_d) bf16(k_d) (fp32 accumulate) - sum_d q_d k_d |
+//      <= (2^-7 (1 + 2^-9) + DP 2^-23) * sum_d |q_d||k_d|  <=  FILT_EPS * ||q||_2 * ||k||_2 .
+// A key can only belong to the k+1 largest exact logits if its screened logit exceeds the current
+// exact (k+1)-th largest minus that margin (with max_i ||k_i|| for ||k||).  Every such candidate is
+// re-scored EXACTLY in fp32 (the wave computes sum_d (w_d x_d) k_d cooperatively from the fp32
+// tables) and only exact values enter the top-(k+1) list, so the kept set is the fp32 one.
+// Workgroup = 8 waves x 32 queries of one column sharing one key stream (stages of 128 keys).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define QPBF 256
+#define TKF 128
+#define FILT_EPS 8.0e-3f
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int KS, int KCAP>
+__global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
+    constexpr int DP = KS * 16;
+    constexpr int RSTR = DP * 2 + 16;        // LDS row stride in bytes: conflict-free ds_read_b128
+    constexpr int CPR = DP / 8;              // 16-byte chunks per key row
+    constexpr int NCH = TKF * CPR;
+    constexpr int NPF = (NCH + 511) / 512;
+    constexpr int NE = DP / 64;              // fp32 elements per lane in the cooperative exact dot
+    extern __shared__ __attribute__((aligned(16))) char fsm[];
+    auto kbuf = [&](int b) -> char * { return fsm + b * (TKF * RSTR); };
+    auto kidx_of = [&](int b) -> int * { return reinterpret_cast<int *>(fsm + 2 * TKF * RSTR) + b * TKF; };
+    __shared__ int s_col;
+
+    const int nblocks = p.qb_start[p.C];
+    const int blk = p.blk_lo + (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    if (tid == 0) s_col = block_column(p.qb_start, p.C, blk);
+    __syncthreads();
+    const int c = s_col;
+    const int nk = p.nk[c];
+    // this launch streams key-list positions [key_lo, key_hi): a chunk small enough to stay in the
+    // Infinity Cache while every workgroup of the group reads it; lists are parked in between
+    const int key_lo = p.key_lo;
+    const int key_hi = p.key_hi < nk ? p.key_hi : nk;
+    if (!(key_lo < nk || (nk == 0 && key_lo == 0))) return;      // column exhausted by an earlier launch
+    const bool first_chunk = key_lo == 0, last_chunk = p.key_hi >= nk;
+    const int32_t *kl = p.klist + (int64_t)c * p.Nk;
+    const int off_c = p.offsets[c];
+    const int d_c = p.offsets[c + 1] - off_c;
+    const int64_t slot = (int64_t)blk * QPBF + wid * 32 + r32;
+    const int qrow = p.qlist[slot];
+
+    // query operand: bf16(W[c][k] * x_q[k]) for k = 16 st + 8 h + j, and the margin from ||q||
+    bf16x8 breg[KS];
+    float qn2 = 0.f;
+    {
+        const float *wq = p.Wp + (int64_t)c * DP + 8 * h;
+        const float *xq = p.Xqp + (int64_t)(qrow < 0 ? 0 : qrow) * DP + 8 * h;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 16 * st + 4 * j4);
+                f32x4 xv = *reinterpret_cast<const f32x4 *>(xq + 16 * st + 4 * j4);
+                if (qrow < 0) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float q = wv[j] * xv[j];
+                    qn2 += q * q;
+                    breg[st][4 * j4 + j] = (__bf16)q;
+                }
+            }
+        }
+    }
+    qn2 += __shfl_xor(qn2, 32);
+    const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
+    float wreg[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) wreg[i] = p.Wp[(int64_t)c * DP + lane + 64 * i];
+
+    float lst[KCAP];
+    int lpos[KCAP];
+    const int ndummy = KCAP - (p.k + 1);
+    float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * 512 + tid;
+    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * 512 + tid;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        lst[i] = (i < ndummy || qrow < 0) ? INFINITY : -INFINITY;   // padding slots never take candidates
+        lpos[i] = -1;
+        if (!first_chunk && i >= ndummy) {
+            lst[i] = sval[(int64_t)(i - ndummy) * 512];
+            lpos[i] = spos[(int64_t)(i - ndummy) * 512];
+        }
+    }
+
+    // key staging: 16-byte chunks of bf16 rows gathered through klist
+    uint4 pf[NPF];
+    int pfk[NPF];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + 512 * i;
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int pos = key_lo + t * TKF + row;
+            const int kidx = (idx < NCH && pos < key_hi) ? kl[pos] : -1;
+            pfk[i] = kidx;
+            pf[i] = uint4{0u, 0u, 0u, 0u};
+            if (kidx >= 0) pf[i] = *reinterpret_cast<const uint4 *>(p.Xkh + (int64_t)kidx * DP + ch * 8);
+        }
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + 512 * i;
+            if (idx < NCH) {
+                const int row = idx / CPR, ch = idx - row * CPR;
+                *reinterpret_cast<uint4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
+                if (ch == 0) kidx_of(b)[row] = pfk[i];
+            }
+        }
+    };
+
+    const int nst = (key_hi - key_lo + TKF - 1) / TKF;
+    if (nst > 0) { prefetch(0); commit(0); }
+    __syncthreads();
+
+    for (int t = 0; t < nst; ++t) {
+        const int cb = t & 1;
+        if (t + 1 < nst) prefetch(t + 1);
+        const int rem_stage = key_hi - key_lo - t * TKF;
+#pragma unroll 1
+        for (int sub = 0; sub < TKF / 32; ++sub) {
+            const int rem = rem_stage - sub * 32;       // valid key rows in this 32-key tile
+            if (rem <= 0) break;
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+            const char *Ab = kbuf(cb) + (sub * 32 + r32) * RSTR + h * 16;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const bf16x8 a8 = *reinterpret_cast<const bf16x8 *>(Ab + st * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, breg[st], acc, 0, 0, 0);
+            }
+            const float thr_adj = lst[KCAP - 1] - qe;
+            unsigned cm = 0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                const bool ok = (kr < rem) && (acc[g] > thr_adj);
+                cm |= ok ? (1u << g) : 0u;
+            }
+#ifdef FILT_NO_EVENTS
+            cm = 0;
+#endif
+            unsigned long long bal = __ballot(cm != 0);
+            while (bal) {                                    // rare: exact fp32 re-scoring, one candidate at a time
+                const int src = __ffsll((long long)bal) - 1;
+                const unsigned cms = (unsigned)__builtin_amdgcn_readlane((int)cm, src);
+                const int g = __ffs((int)cms) - 1;
+                const int kr = sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * (src >> 5);
+                const int kidx = kidx_of(cb)[kr];
+                const int qr = __builtin_amdgcn_readlane(qrow, src);
+                const float *xq = p.Xqp + (int64_t)qr * DP + lane;
+                const float *xk = p.Xkp + (int64_t)kidx * DP + lane;
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) part = fmaf(wreg[i] * xq[64 * i], xk[64 * i], part);
+                const float sv = wave_sum(part);
+                if (lane == src) {
+                    cm &= ~(1u << g);
+                    if (sv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, sv, key_lo + t * TKF + kr);
+                    // logits screened against the old threshold may have dropped out: re-screen
+                    const float ta = lst[KCAP - 1] - qe;
+#pragma unroll
+                    for (int g2 = 0; g2 < 16; ++g2)
+                        if (!(acc[g2] > ta)) cm &= ~(1u << g2);
+                }
+                bal = __ballot(cm != 0);
+            }
+        }
+        if (t + 1 < nst) commit(cb ^ 1);
+        __syncthreads();
+    }
+    if (last_chunk) {
+        topk_finish<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i)
+            if (i >= ndummy) {
+                sval[(int64_t)(i - ndummy) * 512] = lst[i];
+                spos[(int64_t)(i - ndummy) * 512] = lpos[i];
+            }
+    }
+}
+
+// keys -> bf16, and the largest key 2-norm (rounded up) for the screening margin; one wave per row
+__global__ void k_keys_bf16(const float *__restrict__ Xkp, int64_t rows, int DP, __bf16 *__restrict__ Xkh,
+                            unsigned *__restrict__ kmax_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float best = 0.f;
+    for (int64_t r = row0; r < rows; r += nw) {
+        float s2 = 0.f;
+        for (int e = lane; e < DP; e += 64) {
+            const float v = Xkp[r * DP + e];
+            Xkh[r * DP + e] = (__bf16)v;
+            s2 += v * v;
+        }
+        s2 = wave_sum(s2);
+        best = fmaxf(best, sqrtf(s2) * 1.000001f);
+    }
+    if (lane == 0) atomicMax(kmax_bits, __float_as_uint(best));     // non-negative floats order like their bits
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,13 +643,14 @@ __global__ void k_scan_chunks(int32_t *__restrict__ cnt, int nchunks, int32_t *_
     for (int i = b; i < e; ++i) { const int v = row[i]; row[i] = run; run += v; }
 }
 
-// qb_start[c] = sum_{c'<c} ceil((rows - obs[c'])/128)
-__global__ void k_qb_start(const int32_t *__restrict__ obs_q, int64_t rows, int C, int32_t *__restrict__ qb_start) {
+// qb_start[c] = sum_{c'<c} ceil((rows - obs[c'])/qpb)   (qpb = queries per workgroup of the selection kernel)
+__global__ void k_qb_start(const int32_t *__restrict__ obs_q, int64_t rows, int C, int qpb,
+                           int32_t *__restrict__ qb_start) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         int run = 0;
         for (int c = 0; c < C; ++c) {
             qb_start[c] = run;
-            run += (int)(((int64_t)rows - obs_q[c] + QPB - 1) / QPB);
+            run += (int)(((int64_t)rows - obs_q[c] + qpb - 1) / qpb);
         }
         qb_start[C] = run;
     }
@@ -415,7 +661,7 @@ __global__ void k_qb_start(const int32_t *__restrict__ obs_q, int64_t rows, int 
 template <bool WRITE_K, bool WRITE_Q>
 __global__ void k_fill_lists(const uint8_t *__restrict__ m, int64_t rows, int C, int nchunks,
                              const int32_t *__restrict__ cnt_excl, int32_t *__restrict__ klist, int64_t kstride,
-                             const int32_t *__restrict__ qb_start, int32_t *__restrict__ qlist) {
+                             const int32_t *__restrict__ qb_start, int qpb, int32_t *__restrict__ qlist) {
     __shared__ int wsum[4];
     const int64_t row0 = (int64_t)blockIdx.x * 256;
     const int64_t row = row0 + threadIdx.x;
@@ -435,7 +681,7 @@ __global__ void k_fill_lists(const uint8_t *__restrict__ m, int64_t rows, int C,
         if (WRITE_Q && inb && !obs) {
             const int64_t miss_before = row0 - obs_before;          // missing rows in earlier chunks
             const int pos_miss = threadIdx.x - pos_obs;             // missing rows before me in the chunk
-            qlist[(int64_t)qb_start[c] * QPB + miss_before + pos_miss] = (int32_t)row;
+            qlist[(int64_t)qb_start[c] * qpb + miss_before + pos_miss] = (int32_t)row;
         }
         __syncthreads();
     }
@@ -446,15 +692,6 @@ __global__ void k_fill_lists(const uint8_t *__restrict__ m, int64_t rows, int C,
 // are compacted into a second query list, one block = 128 pairs of ONE column as before, and go
 // through the MODE_FILL pass.  cnt2[c] = flagged pairs of column c, cur2[c] = append cursor.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int block_column(const int32_t *qb_start, int C, int b) {
-    int lo = 0, hi = C;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (qb_start[mid] <= b) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 template <bool WRITE>
 __global__ void k_compact_flagged(const int32_t *__restrict__ flag, const int32_t *__restrict__ qlist,
                                   const float *__restrict__ tau, const float *__restrict__ smax,
@@ -464,7 +701,7 @@ __global__ void k_compact_flagged(const int32_t *__restrict__ flag, const int32_
     __shared__ int s_base, s_n;
     if ((int)blockIdx.x >= qb_start[C]) return;
     const int c = block_column(qb_start, C, blockIdx.x);
-    const int64_t slot = (int64_t)blockIdx.x * QPB + threadIdx.x;       // blockDim.x == QPB
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim.x == queries per source block
     const int q = qlist[slot];
     const bool f = q >= 0 && flag[slot] != 0;
     if (threadIdx.x == 0) s_n = 0;
@@ -508,7 +745,7 @@ __global__ void k_write_debug(const int32_t *__restrict__ qlist, const float *__
                               float *__restrict__ out_tau, int32_t *__restrict__ out_nvalid) {
     if ((int)blockIdx.x >= qb_start[C]) return;
     const int c = block_column(qb_start, C, blockIdx.x);
-    const int64_t slot = (int64_t)blockIdx.x * QPB + threadIdx.x;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = qlist[slot];
     if (q < 0) return;
     if (out_tau) out_tau[(int64_t)q * C + c] = tau[slot];
@@ -521,31 +758,53 @@ __global__ void k_write_debug(const int32_t *__restrict__ qlist, const float *__
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int ks4_for(int D) { return D <= 64 ? 8 : D <= 128 ? 16 : D <= 192 ? 24 : D <= 256 ? 32 : 0; }
 
+// one compacted list of open pairs: 128 pairs of one column per workgroup
+struct PairList {
+    int32_t *qlist, *qb_start, *cnt, *flag;   // cnt: [C] counts then [C] cursors
+    float *tau, *smax;
+};
+
 struct AttnWs {
     float *Xkp, *Xqp, *Wp;
-    int32_t *klist, *nk, *obs_q, *cnt_k, *cnt_q, *qlist, *qb_start, *offsets;
-    float *tau, *smax;
+    __bf16 *Xkh;
+    int32_t *klist, *nk, *obs_q, *cnt_k, *cnt_q, *offsets;
     uint32_t *prefix;
     int32_t *rank;
-    int32_t *flags;            // [0] = 1 when queries alias keys (set by prepare)
-    // tie fallback of the register path
-    int32_t *flag, *qlist2, *qb_start2, *cnt2;   // cnt2: [C] counts then [C] cursors
-    float *tau2, *smax2;
+    int32_t *flags;            // [0] = 1 when queries alias keys (set by prepare); [1] = bits of max key norm
+    PairList L1;               // primary list (128 or 256 pairs per workgroup, by mode)
+    PairList L2, L3;           // fallback lists (128 per workgroup)
+    float *st_val;             // parked lists of the filter kernel, FILT_GROUP workgroups
+    int32_t *st_pos;
     size_t total;
-    int64_t qb_max;
+    int64_t slots;             // capacity of every per-pair array
     int nchunk_k, nchunk_q;
 };
 
-static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int D, bool same) {
+#define FILT_GROUP 16384       // workgroups per launch group of the filter kernel (bounds the parked state)
+// key-list positions per launch: the keys (fp32 + bf16 rows) of a chunk stay in the Infinity Cache.
+// DDG_FILT_CHUNK (multiple of 128) overrides it: tests use a small value to cover the chunked path.
+static int64_t filt_chunk() {
+    static int64_t v = 0;
+    if (v == 0) {
+        const char *e = getenv("DDG_FILT_CHUNK");
+        int64_t c = e ? atoll(e) : 65536;
+        if (c < 128) c = 128;
+        v = (c / 128) * 128;
+    }
+    return v;
+}
+
+static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int D, int64_t k, bool same) {
     const int DP = ks4_for(D) * 8;
     size_t o = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + o : nullptr; o += al256(bytes); return p; };
     w.nchunk_k = (int)ceil_div64(Nk, 256);
     w.nchunk_q = (int)ceil_div64(Nq, 256);
-    w.qb_max = (Nq * C) / QPB + C;
+    w.slots = Nq * C + (int64_t)QPBF * C;       // pairs + per-column padding at either block size
     w.Xkp = (float *)take((size_t)Nk * DP * 4);
     w.Xqp = (float *)take((size_t)Nq * DP * 4);
     if (same) w.Xqp = w.Xkp;
+    w.Xkh = (__bf16 *)take((size_t)Nk * DP * 2);
     w.Wp = (float *)take((size_t)C * DP * 4);
     w.klist = (int32_t *)take((size_t)C * Nk * 4);
     w.nk = (int32_t *)take((size_t)C * 4);
@@ -553,88 +812,170 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
     w.cnt_k = (int32_t *)take((size_t)C * w.nchunk_k * 4);
     w.cnt_q = (int32_t *)take((size_t)C * w.nchunk_q * 4);
     if (same) w.cnt_q = w.cnt_k;
-    w.qlist = (int32_t *)take((size_t)w.qb_max * QPB * 4);
-    w.qb_start = (int32_t *)take((size_t)(C + 1) * 4);
     w.offsets = (int32_t *)take((size_t)(C + 1) * 4);
-    w.tau = (float *)take((size_t)w.qb_max * QPB * 4);
-    w.smax = (float *)take((size_t)w.qb_max * QPB * 4);
-    w.prefix = (uint32_t *)take((size_t)w.qb_max * QPB * 4);
-    w.rank = (int32_t *)take((size_t)w.qb_max * QPB * 4);
+    w.prefix = (uint32_t *)take((size_t)w.slots * 4);
+    w.rank = (int32_t *)take((size_t)w.slots * 4);
     w.flags = (int32_t *)take(256);
-    w.flag = (int32_t *)take((size_t)w.qb_max * QPB * 4);
-    w.qlist2 = (int32_t *)take((size_t)w.qb_max * QPB * 4);
-    w.tau2 = (float *)take((size_t)w.qb_max * QPB * 4);
-    w.smax2 = (float *)take((size_t)w.qb_max * QPB * 4);
-    w.qb_start2 = (int32_t *)take((size_t)(C + 1) * 4);
-    w.cnt2 = (int32_t *)take((size_t)2 * C * 4);
+    PairList *ls[3] = {&w.L1, &w.L2, &w.L3};
+    for (PairList *l : ls) {
+        l->qlist = (int32_t *)take((size_t)w.slots * 4);
+        l->tau = (float *)take((size_t)w.slots * 4);
+        l->smax = (float *)take((size_t)w.slots * 4);
+        l->flag = (int32_t *)take((size_t)w.slots * 4);
+        l->qb_start = (int32_t *)take((size_t)(C + 1) * 4);
+        l->cnt = (int32_t *)take((size_t)2 * C * 4);
+    }
+    {
+        const int64_t kk = k > DDG_MAX_TOPK_REG ? 0 : (k < 1 ? 1 : k) + 1;
+        const int64_t grp = w.slots / QPBF + C < FILT_GROUP ? w.slots / QPBF + C : FILT_GROUP;
+        const size_t st = Nk > filt_chunk() ? (size_t)grp * 512 * kk * 4 : 0;
+        w.st_val = (float *)take(st);
+        w.st_pos = (int32_t *)take(st);
+    }
     w.total = o;
 }
 
 extern "C" size_t ddg_attn_workspace_bytes(int64_t Nq, int64_t Nk, int C, int D, int64_t k) {
-    (void)k;
     if (ks4_for(D) == 0 || Nq < 0 || Nk < 0 || C < 1) return 0;
     AttnWs w;
-    attn_carve(w, nullptr, Nq, Nk, C, D, false);   // the layout does not depend on aliasing
+    attn_carve(w, nullptr, Nq, Nk, C, D, k > Nk ? Nk : k, false);   // the layout does not depend on aliasing or mode
     return w.total;
 }
 
-template <int KS4, int MODE, int KCAP>
-static int launch_attn(const AttnArgs &a, int64_t qb_max, size_t extra_bytes, hipStream_t s) {
-    const size_t lds = (size_t)2 * TK * (KS4 * 8 + 4) * 4 + extra_bytes;
+static int set_lds_attr(const void *fn, size_t lds, size_t &granted) {
     if (lds > 160 * 1024 - 64) return DDG_E_UNSUPPORTED;
-    static size_t attr_lds = 48 * 1024;   // dynamic LDS above the default limit must be opted into
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_attn<KS4, MODE, KCAP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > granted) {   // dynamic LDS above the default limit must be opted into
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             fprintf(stderr, "ddgani: hipFuncSetAttribute(%zu): %s\n", lds, hipGetErrorString(e));
             return DDG_E_LAUNCH;
         }
-        attr_lds = lds;
+        granted = lds;
     }
-    k_attn<KS4, MODE, KCAP><<<(unsigned)qb_max, 256, lds, s>>>(a);
+    return DDG_OK;
+}
+
+template <int KS4, int MODE, int KCAP>
+static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_bytes, hipStream_t s) {
+    const size_t lds = (size_t)2 * TK * (KS4 * 8 + 4) * 4 + extra_bytes;
+    static size_t granted = 48 * 1024;
+    int rc = set_lds_attr((const void *)k_attn<KS4, MODE, KCAP>, lds, granted);
+    if (rc) return rc;
+    k_attn<KS4, MODE, KCAP><<<(unsigned)nblocks_max, 256, lds, s>>>(a);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+template <int KS, int KCAP>
+static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
+    const size_t lds = (size_t)2 * TKF * (KS * 32 + 16) + 2 * TKF * 4;
+    static size_t granted = 48 * 1024;
+    int rc = set_lds_attr((const void *)k_attn_filt<KS, KCAP>, lds, granted);
+    if (rc) return rc;
+    // groups of workgroups (outer) x chunks of the key lists (inner): every launch of a group streams
+    // the same chunk, so it is served from the Infinity Cache / L2 instead of HBM once per workgroup
+    AttnArgs b = a;
+    for (int64_t g0 = 0; g0 < nblocks_max; g0 += FILT_GROUP) {
+        const int64_t gn = nblocks_max - g0 < FILT_GROUP ? nblocks_max - g0 : FILT_GROUP;
+        b.blk_lo = (int)g0;
+        const int64_t CH = filt_chunk();
+        for (int64_t k0 = 0; k0 == 0 || k0 < a.Nk; k0 += CH) {
+            b.key_lo = (int)k0;
+            b.key_hi = (int)(k0 + CH < a.Nk ? k0 + CH : ((int64_t)1 << 31) - 1);
+            k_attn_filt<KS, KCAP><<<(unsigned)gn, 512, lds, s>>>(b);
+        }
+    }
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
 
 template <int KS4>
-static int run_select(AttnArgs &a, int64_t qb_max, hipStream_t s) {
+static int run_select(AttnArgs &a, int64_t nb, int mode, hipStream_t s) {
     int rc;
-    if (a.k < 16) return launch_attn<KS4, MODE_TOPK, 16>(a, qb_max, 0, s);
-    if (a.k <= DDG_MAX_TOPK_REG) return launch_attn<KS4, MODE_TOPK, 32>(a, qb_max, 0, s);
+    if (a.k <= DDG_MAX_TOPK_REG && mode == DDG_ATTN_BF16_FILTER) {
+        if (a.k < 16) return launch_filt<KS4 / 2, 16>(a, nb, s);
+        return launch_filt<KS4 / 2, 32>(a, nb, s);
+    }
+    if (a.k < 16) return launch_attn<KS4, MODE_TOPK, 16>(a, nb, 0, s);
+    if (a.k <= DDG_MAX_TOPK_REG) return launch_attn<KS4, MODE_TOPK, 32>(a, nb, 0, s);
     for (int L = 0; L < 5; ++L) {
         a.level = L;
-        rc = launch_attn<KS4, MODE_HIST, 1>(a, qb_max, (size_t)QPB * HSTRIDE * 4, s);
+        rc = launch_attn<KS4, MODE_HIST, 1>(a, nb, (size_t)QPB * HSTRIDE * 4, s);
         if (rc) return rc;
     }
     return DDG_OK;
 }
 
 template <int KS4>
-static int run_fill(AttnArgs &a, int64_t qb_max, int dcmax, hipStream_t s) {
+static int run_fill(AttnArgs &a, int64_t nb, int dcmax, hipStream_t s) {
     a.dcs = dcmax | 1;
-    return launch_attn<KS4, MODE_FILL, 1>(a, qb_max, (size_t)256 * a.dcs * 4, s);
+    return launch_attn<KS4, MODE_FILL, 1>(a, nb, (size_t)256 * a.dcs * 4, s);
 }
 
-static int attn_check_dims(int64_t Nq, int64_t Nk, int C, int D) {
+static int dispatch_select(AttnArgs &a, int64_t nb, int mode, int D, hipStream_t s) {
+    switch (ks4_for(D)) {
+        case 8: return run_select<8>(a, nb, mode, s);
+        case 16: return run_select<16>(a, nb, mode, s);
+        case 24: return run_select<24>(a, nb, mode, s);
+        case 32: return run_select<32>(a, nb, mode, s);
+    }
+    return DDG_E_UNSUPPORTED;
+}
+
+static int dispatch_fill(AttnArgs &a, int64_t nb, int dcmax, int D, hipStream_t s) {
+    switch (ks4_for(D)) {
+        case 8: return run_fill<8>(a, nb, dcmax, s);
+        case 16: return run_fill<16>(a, nb, dcmax, s);
+        case 24: return run_fill<24>(a, nb, dcmax, s);
+        case 32: return run_fill<32>(a, nb, dcmax, s);
+    }
+    return DDG_E_UNSUPPORTED;
+}
+
+static int attn_check_dims(int64_t Nq, int64_t Nk, int C, int D, int mode) {
     if (Nq < 0 || Nk < 1 || C < 1 || D < 1) return DDG_E_ARG;
+    if (mode != DDG_ATTN_F32 && mode != DDG_ATTN_BF16_FILTER) return DDG_E_ARG;
     if (ks4_for(D) == 0 || Nk >= (int64_t)1 << 31 || (Nq * C) / QPB + C >= (int64_t)1 << 31) return DDG_E_UNSUPPORTED;
     return DDG_OK;
 }
 
-static void attn_args(AttnArgs &a, const AttnWs &w, int64_t Nk, int C, int D, int k) {
-    a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.klist = w.klist; a.nk = w.nk; a.qlist = w.qlist;
-    a.qb_start = w.qb_start; a.offsets = w.offsets; a.tau = w.tau; a.smax = w.smax; a.prefix = w.prefix;
-    a.rank = w.rank; a.flag = w.flag; a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
+// pairs per workgroup of the primary list
+static inline int primary_qpb(int mode, int64_t k) {
+    return (mode == DDG_ATTN_BF16_FILTER && k <= DDG_MAX_TOPK_REG) ? QPBF : QPB;
+}
+static inline int64_t blocks_max(const AttnWs &w, int C, int qpb) { return w.slots / qpb + C; }
+
+static void attn_args(AttnArgs &a, const AttnWs &w, const PairList &l, int64_t Nk, int C, int D, int k) {
+    a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.Xkh = w.Xkh; a.kmax = reinterpret_cast<const float *>(w.flags + 1);
+    a.st_val = w.st_val; a.st_pos = w.st_pos; a.key_lo = 0; a.key_hi = 0x7fffffff; a.blk_lo = 0;
+    a.klist = w.klist; a.nk = w.nk; a.qlist = l.qlist; a.qb_start = l.qb_start; a.offsets = w.offsets;
+    a.tau = l.tau; a.smax = l.smax; a.flag = l.flag; a.prefix = w.prefix; a.rank = w.rank;
+    a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
     a.D = D; a.DP = ks4_for(D) * 8; a.k = k; a.level = 0; a.dcs = 1;
 }
 
-// phase 1: padded operands + per-column key / query index lists
+// flagged pairs of `src` (workgroups of qpb_src pairs) -> `dst` (workgroups of 128)
+static int compact_pairs(const AttnWs &w, const PairList &src, int qpb_src, const PairList &dst, int C, hipStream_t s) {
+    const unsigned g = (unsigned)blocks_max(w, C, qpb_src);
+    if (hipMemsetAsync(dst.cnt, 0, (size_t)2 * C * 4, s) != hipSuccess) return DDG_E_LAUNCH;
+    if (hipMemsetAsync(dst.qlist, 0xFF, (size_t)w.slots * 4, s) != hipSuccess) return DDG_E_LAUNCH;
+    k_compact_flagged<false><<<g, qpb_src, 0, s>>>(src.flag, src.qlist, src.tau, src.smax, src.qb_start, C, dst.cnt,
+                                                   dst.cnt + C, dst.qb_start, dst.qlist, dst.tau, dst.smax);
+    k_qb_start2<<<1, 64, 0, s>>>(dst.cnt, C, dst.qb_start);
+    k_compact_flagged<true><<<g, qpb_src, 0, s>>>(src.flag, src.qlist, src.tau, src.smax, src.qb_start, C, dst.cnt,
+                                                  dst.cnt + C, dst.qb_start, dst.qlist, dst.tau, dst.smax);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// phase 1: padded operands (+ bf16 keys and their largest norm in filter mode) and the per-column
+// key / query index lists
 extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
                                 const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
-                                int64_t Nk, int C, int D, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!Xq0 || !mq || !Xk0 || !mk || !W || !offsets_host) return DDG_E_ARG;
-    int rc = attn_check_dims(Nq, Nk, C, D);
+                                int64_t Nk, int C, int D, int64_t k, int mode, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    if (!Xq0 || !mq || !Xk0 || !mk || !W || !offsets_host || k < 1) return DDG_E_ARG;
+    int rc = attn_check_dims(Nq, Nk, C, D, mode);
     if (rc) return rc;
     if (q_row_offset < 0 || q_row_offset + Nq > Nk) return DDG_E_ARG;
     if (offsets_host[0] != 0 || offsets_host[C] != D) return DDG_E_ARG;
@@ -643,76 +984,81 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
     if (Nq == 0) return DDG_OK;
     const bool same = (Xq0 == Xk0 && mq == mk && Nq == Nk);
     AttnWs w;
-    attn_carve(w, (char *)workspace, Nq, Nk, C, D, same);
+    attn_carve(w, (char *)workspace, Nq, Nk, C, D, k > Nk ? Nk : k, same);
     if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int DP = ks4_for(D) * 8;
+    const int qpb = primary_qpb(mode, k > Nk ? Nk : k);
 
     if (hipMemcpyAsync(w.offsets, offsets_host, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess)
         return DDG_E_LAUNCH;
-    if (hipMemsetAsync(w.qlist, 0xFF, (size_t)w.qb_max * QPB * 4, s) != hipSuccess) return DDG_E_LAUNCH;
-    if (hipMemsetAsync(w.flags, same ? 1 : 0, 4, s) != hipSuccess) return DDG_E_LAUNCH;
+    if (hipMemsetAsync(w.L1.qlist, 0xFF, (size_t)w.slots * 4, s) != hipSuccess) return DDG_E_LAUNCH;
+    if (hipMemsetAsync(w.flags, 0, 8, s) != hipSuccess) return DDG_E_LAUNCH;
+    if (same && hipMemsetAsync(w.flags, 1, 1, s) != hipSuccess) return DDG_E_LAUNCH;
 
     auto egrid = [](int64_t n) { int64_t g = ceil_div64(n, 256); return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
     k_pad_rows<<<egrid(Nk * DP), 256, 0, s>>>(Xk0, w.Xkp, Nk, D, DP);
     if (!same) k_pad_rows<<<egrid(Nq * DP), 256, 0, s>>>(Xq0, w.Xqp, Nq, D, DP);
     k_pad_rows<<<egrid((int64_t)C * DP), 256, 0, s>>>(W, w.Wp, C, D, DP);
+    if (qpb == QPBF)
+        k_keys_bf16<<<egrid(Nk * 64), 256, 0, s>>>(w.Xkp, Nk, DP, w.Xkh, reinterpret_cast<unsigned *>(w.flags + 1));
 
     k_count_obs<<<w.nchunk_k, 256, 0, s>>>(mk, Nk, C, w.nchunk_k, w.cnt_k);
     k_scan_chunks<<<C, 256, 0, s>>>(w.cnt_k, w.nchunk_k, w.nk);
     if (same) {
-        k_qb_start<<<1, 64, 0, s>>>(w.nk, Nq, C, w.qb_start);
-        k_fill_lists<true, true><<<w.nchunk_k, 256, 0, s>>>(mk, Nk, C, w.nchunk_k, w.cnt_k, w.klist, Nk, w.qb_start, w.qlist);
+        k_qb_start<<<1, 64, 0, s>>>(w.nk, Nq, C, qpb, w.L1.qb_start);
+        k_fill_lists<true, true><<<w.nchunk_k, 256, 0, s>>>(mk, Nk, C, w.nchunk_k, w.cnt_k, w.klist, Nk, w.L1.qb_start,
+                                                            qpb, w.L1.qlist);
     } else {
         k_count_obs<<<w.nchunk_q, 256, 0, s>>>(mq, Nq, C, w.nchunk_q, w.cnt_q);
         k_scan_chunks<<<C, 256, 0, s>>>(w.cnt_q, w.nchunk_q, w.obs_q);
-        k_qb_start<<<1, 64, 0, s>>>(w.obs_q, Nq, C, w.qb_start);
-        k_fill_lists<true, false><<<w.nchunk_k, 256, 0, s>>>(mk, Nk, C, w.nchunk_k, w.cnt_k, w.klist, Nk, w.qb_start, w.qlist);
-        k_fill_lists<false, true><<<w.nchunk_q, 256, 0, s>>>(mq, Nq, C, w.nchunk_q, w.cnt_q, w.klist, Nk, w.qb_start, w.qlist);
+        k_qb_start<<<1, 64, 0, s>>>(w.obs_q, Nq, C, qpb, w.L1.qb_start);
+        k_fill_lists<true, false><<<w.nchunk_k, 256, 0, s>>>(mk, Nk, C, w.nchunk_k, w.cnt_k, w.klist, Nk,
+                                                             w.L1.qb_start, qpb, w.L1.qlist);
+        k_fill_lists<false, true><<<w.nchunk_q, 256, 0, s>>>(mq, Nq, C, w.nchunk_q, w.cnt_q, w.klist, Nk,
+                                                             w.L1.qb_start, qpb, w.L1.qlist);
     }
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
 
-// phase 2: one similarity pass.  out_code <- Xq0, then
-//   k <= DDG_MAX_TOPK_REG: the k+1 largest logits and their key rows per (query row, column) pair
-//     in registers; pairs without a tie at the k-th logit are filled right here (softmax over
-//     the kept k, gather of the key values), the others are flagged for phase 3;
-//   larger k: 5-level radix select of tau (5 similarity passes), every pair is filled in phase 3.
-extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, int D, int64_t k,
+// phase 2: one similarity pass over every open pair.  out_code <- Xq0, then
+//   k <= DDG_MAX_TOPK_REG: the k+1 largest logits and their key rows per pair are kept in registers
+//     (fp32 MFMA, or bf16 MFMA screening + exact fp32 re-scoring in DDG_ATTN_BF16_FILTER mode); pairs
+//     without a tie at the k-th logit are filled right here, the others are flagged for phase 3;
+//   larger k: 5-level radix select of tau (5 fp32 similarity passes), every pair is filled in phase 3.
+extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, int D, int64_t k, int mode,
                                int queries_alias_keys, float *out_code, void *workspace, size_t workspace_bytes,
                                void *stream) {
     if (!Xq0 || !out_code) return DDG_E_ARG;
-    int rc = attn_check_dims(Nq, Nk, C, D);
+    int rc = attn_check_dims(Nq, Nk, C, D, mode);
     if (rc) return rc;
     if (k < 1) return DDG_E_ARG;
     if (Nq == 0) return DDG_OK;
     AttnWs w;
-    attn_carve(w, (char *)workspace, Nq, Nk, C, D, queries_alias_keys != 0);
+    attn_carve(w, (char *)workspace, Nq, Nk, C, D, k > Nk ? Nk : k, queries_alias_keys != 0);
     if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (out_code != Xq0 &&
         hipMemcpyAsync(out_code, Xq0, (size_t)Nq * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return DDG_E_LAUNCH;
     AttnArgs a;
-    attn_args(a, w, Nk, C, D, (int)(k > Nk ? Nk : k));
+    const int kk = (int)(k > Nk ? Nk : k);
+    attn_args(a, w, w.L1, Nk, C, D, kk);
     a.out_code = out_code;
-    switch (ks4_for(D)) {
-        case 8: return run_select<8>(a, w.qb_max, s);
-        case 16: return run_select<16>(a, w.qb_max, s);
-        case 24: return run_select<24>(a, w.qb_max, s);
-        case 32: return run_select<32>(a, w.qb_max, s);
-    }
-    return DDG_E_UNSUPPORTED;
+    return dispatch_select(a, blocks_max(w, C, primary_qpb(mode, kk)), mode, D, s);
 }
 
-// phase 3: softmax-weighted accumulation over {s >= tau} (second similarity pass) for the pairs
-// phase 2 left open: all of them on the radix path, only the tie-flagged ones on the register path
-extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk, int C, int D, int64_t k,
+// phase 3: the pairs phase 2 left open.
+//   radix path: every pair, softmax-weighted accumulation over {s >= tau} (one more similarity pass);
+//   register path, fp32: tie-flagged pairs -> compacted list -> threshold pass;
+//   register path, bf16 filter: flagged pairs -> compacted list -> fp32 register kernel (its tau and
+//     logits come from one arithmetic) -> its flagged pairs -> second compacted list -> threshold pass.
+extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk, int C, int D, int64_t k, int mode,
                              int queries_alias_keys, float *out_code, float *out_tau, int32_t *out_nvalid,
                              void *workspace, size_t workspace_bytes, void *stream) {
     if (!offsets_host || !out_code) return DDG_E_ARG;
-    int rc = attn_check_dims(Nq, Nk, C, D);
+    int rc = attn_check_dims(Nq, Nk, C, D, mode);
     if (rc) return rc;
     if (k < 1) return DDG_E_ARG;
     if (Nq == 0) return DDG_OK;
@@ -723,48 +1069,48 @@ extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk
         if (d > dcmax) dcmax = d;
     }
     AttnWs w;
-    attn_carve(w, (char *)workspace, Nq, Nk, C, D, queries_alias_keys != 0);
+    attn_carve(w, (char *)workspace, Nq, Nk, C, D, k > Nk ? Nk : k, queries_alias_keys != 0);
     if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     AttnArgs a;
     const int kk = (int)(k > Nk ? Nk : k);
-    attn_args(a, w, Nk, C, D, kk);
-    a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
-    if (kk <= DDG_MAX_TOPK_REG) {
-        const unsigned g = (unsigned)w.qb_max;
-        if (hipMemsetAsync(w.cnt2, 0, (size_t)2 * C * 4, s) != hipSuccess) return DDG_E_LAUNCH;
-        if (hipMemsetAsync(w.qlist2, 0xFF, (size_t)w.qb_max * QPB * 4, s) != hipSuccess) return DDG_E_LAUNCH;
-        k_compact_flagged<false><<<g, QPB, 0, s>>>(w.flag, w.qlist, w.tau, w.smax, w.qb_start, C, w.cnt2, w.cnt2 + C,
-                                                   w.qb_start2, w.qlist2, w.tau2, w.smax2);
-        k_qb_start2<<<1, 64, 0, s>>>(w.cnt2, C, w.qb_start2);
-        k_compact_flagged<true><<<g, QPB, 0, s>>>(w.flag, w.qlist, w.tau, w.smax, w.qb_start, C, w.cnt2, w.cnt2 + C,
-                                                  w.qb_start2, w.qlist2, w.tau2, w.smax2);
-        if (out_tau || out_nvalid)
-            k_write_debug<<<g, QPB, 0, s>>>(w.qlist, w.tau, w.qb_start, w.nk, C, out_tau, out_nvalid);
+    const int64_t nb128 = blocks_max(w, C, QPB);
+    if (kk > DDG_MAX_TOPK_REG) {
+        attn_args(a, w, w.L1, Nk, C, D, kk);
+        a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
+        return dispatch_fill(a, nb128, dcmax, D, s);
+    }
+    const int qpb = primary_qpb(mode, kk);
+    if (out_tau || out_nvalid) {
+        k_write_debug<<<(unsigned)blocks_max(w, C, qpb), qpb, 0, s>>>(w.L1.qlist, w.L1.tau, w.L1.qb_start, w.nk, C,
+                                                                     out_tau, out_nvalid);
         DDG_CHECK_LAUNCH();
-        a.qlist = w.qlist2; a.qb_start = w.qb_start2; a.tau = w.tau2; a.smax = w.smax2;
-        a.out_tau = nullptr; a.out_nvalid = nullptr;
     }
-    switch (ks4_for(D)) {
-        case 8: return run_fill<8>(a, w.qb_max, dcmax, s);
-        case 16: return run_fill<16>(a, w.qb_max, dcmax, s);
-        case 24: return run_fill<24>(a, w.qb_max, dcmax, s);
-        case 32: return run_fill<32>(a, w.qb_max, dcmax, s);
+    if ((rc = compact_pairs(w, w.L1, qpb, w.L2, C, s))) return rc;
+    const PairList *open = &w.L2;
+    if (qpb == QPBF) {
+        attn_args(a, w, w.L2, Nk, C, D, kk);
+        a.out_code = out_code;
+        if ((rc = dispatch_select(a, nb128, DDG_ATTN_F32, D, s))) return rc;
+        if ((rc = compact_pairs(w, w.L2, QPB, w.L3, C, s))) return rc;
+        open = &w.L3;
     }
-    return DDG_E_UNSUPPORTED;
+    attn_args(a, w, *open, Nk, C, D, kk);
+    a.out_code = out_code;
+    return dispatch_fill(a, nb128, dcmax, D, s);
 }
 
 extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
                                   const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
-                                  int64_t Nk, int C, int D, int64_t k, float *out_code, float *out_tau,
+                                  int64_t Nk, int C, int D, int64_t k, int mode, float *out_code, float *out_tau,
                                   int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream) {
     if (!out_code || k < 1) return DDG_E_ARG;
-    int rc = ddg_attn_prepare(Xq0, mq, q_row_offset, Xk0, mk, W, offsets_host, Nq, Nk, C, D, workspace,
+    int rc = ddg_attn_prepare(Xq0, mq, q_row_offset, Xk0, mk, W, offsets_host, Nq, Nk, C, D, k, mode, workspace,
                               workspace_bytes, stream);
     if (rc) return rc;
     const int same = (Xq0 == Xk0 && mq == mk && Nq == Nk) ? 1 : 0;
-    rc = ddg_attn_select(Xq0, Nq, Nk, C, D, k, same, out_code, workspace, workspace_bytes, stream);
+    rc = ddg_attn_select(Xq0, Nq, Nk, C, D, k, mode, same, out_code, workspace, workspace_bytes, stream);
     if (rc) return rc;
-    return ddg_attn_fill(offsets_host, Nq, Nk, C, D, k, same, out_code, out_tau, out_nvalid, workspace,
+    return ddg_attn_fill(offsets_host, Nq, Nk, C, D, k, mode, same, out_code, out_tau, out_nvalid, workspace,
                          workspace_bytes, stream);
 }

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import DiscGrads, DiscWeights, GenGrads, GenWeights, TrainBatch, check, lib
 
 PRO_NONE, PRO_ADD_EMB, PRO_BN_RELU, PRO_EMB_RELU = 0, 1, 2, 3
+ATTN_F32, ATTN_BF16_FILTER = 0, 1
 _NAMES8 = ("betas", "alphas", "sqrt_alphas", "one_by_sqrt_alpha_s", "sqrt_beta_s", "alpha_cumulative",
            "sqrt_alpha_cumulative", "sqrt_one_minus_alpha_cumulative")
 
@@ -329,7 +330,7 @@ def train_disc_grads(PG: "GenParams", PD: "DiscParams", grads: ParamGrads, x0, M
 
 # --------------------------------------------------------------------------- a1 + a2
 def attn_topk_fill(Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offset: int = 0, debug: bool = False,
-                   out=None):
+                   out=None, mode: int = ATTN_BF16_FILTER):
     """Row-attention top-k fill (ddg_attn_topk_fill).  Xq0/Xk0: masked encoded rows [N,D] fp32;
     mq/mk: uint8 [N,C]; W: [C,D].  Returns new_code [Nq,D] (+ tau, nvalid when debug)."""
     Nq, D = Xq0.shape
@@ -347,7 +348,7 @@ def attn_topk_fill(Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offse
         nval = torch.full((Nq, Cc), -1, dtype=torch.int32, device=Xq0.device)
     check(lib().ddg_attn_topk_fill(_ptr(Xq0, torch.float32), _ptr(mq, torch.uint8), q_row_offset,
                                    _ptr(Xk0, torch.float32), _ptr(mk, torch.uint8), _ptr(W, torch.float32),
-                                   layout.offsets_host, Nq, Nk, Cc, D, int(k), _ptr(out), _ptr(tau), _ptr(nval),
+                                   layout.offsets_host, Nq, Nk, Cc, D, int(k), int(mode), _ptr(out), _ptr(tau), _ptr(nval),
                                    ws.data_ptr(), ws.numel(), _stream()), "ddg_attn_topk_fill")
     if debug:
         return out, tau, nval
@@ -357,7 +358,9 @@ def attn_topk_fill(Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offse
 class AttnPlan:
     """The three phases of the attention fill on one workspace (ddg_attn_prepare / _select / _fill)."""
 
-    def __init__(self, Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offset: int = 0):
+    def __init__(self, Xq0, mq, Xk0, mk, W, layout: FieldLayout, k: int, q_row_offset: int = 0,
+                 mode: int = ATTN_BF16_FILTER):
+        self.mode = int(mode)
         self.Xq0, self.mq, self.Xk0, self.mk, self.W, self.layout, self.k = Xq0, mq, Xk0, mk, W, layout, int(k)
         self.q_row_offset = q_row_offset
         self.Nq, self.D = Xq0.shape
@@ -372,8 +375,8 @@ class AttnPlan:
         check(lib().ddg_attn_prepare(_ptr(self.Xq0, torch.float32), _ptr(self.mq, torch.uint8), self.q_row_offset,
                                      _ptr(self.Xk0, torch.float32), _ptr(self.mk, torch.uint8),
                                      _ptr(self.W, torch.float32), self.layout.offsets_host, self.Nq, self.Nk,
-                                     self.layout.C, self.D, self.ws.data_ptr(), self.ws.numel(), _stream()),
-              "ddg_attn_prepare")
+                                     self.layout.C, self.D, self.k, self.mode, self.ws.data_ptr(), self.ws.numel(),
+                                     _stream()), "ddg_attn_prepare")
 
     def select(self, out=None):
         """one similarity pass; k <= 31 also fills every pair without a tie at the k-th logit"""
@@ -381,7 +384,7 @@ class AttnPlan:
             out = torch.empty_like(self.Xq0)
         self.out = out
         check(lib().ddg_attn_select(_ptr(self.Xq0, torch.float32), self.Nq, self.Nk, self.layout.C, self.D, self.k,
-                                    self.alias, _ptr(out), self.ws.data_ptr(), self.ws.numel(), _stream()),
+                                    self.mode, self.alias, _ptr(out), self.ws.data_ptr(), self.ws.numel(), _stream()),
               "ddg_attn_select")
         return out
 
@@ -392,6 +395,6 @@ class AttnPlan:
             tau = torch.full((self.Nq, self.layout.C), float("nan"), dtype=torch.float32, device=self.out.device)
             nval = torch.full((self.Nq, self.layout.C), -1, dtype=torch.int32, device=self.out.device)
         check(lib().ddg_attn_fill(self.layout.offsets_host, self.Nq, self.Nk, self.layout.C, self.D, self.k,
-                                  self.alias, _ptr(self.out), _ptr(tau), _ptr(nval), self.ws.data_ptr(),
+                                  self.mode, self.alias, _ptr(self.out), _ptr(tau), _ptr(nval), self.ws.data_ptr(),
                                   self.ws.numel(), _stream()), "ddg_attn_fill")
         return (self.out, tau, nval) if debug else self.out

@@ -242,11 +242,21 @@ int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads
  * Optional debug outputs (NULL to skip): out_tau [Nq,C] (NaN where mq==1, -inf when all
  * valid keys are kept), out_nvalid int32 [Nq,C].
  * ------------------------------------------------------------------------------------- */
+/* mode: how the similarity of the register path (k <= DDG_MAX_TOPK_REG) is evaluated.
+ *   DDG_ATTN_F32          fp32 MFMA (v_mfma_f32_32x32x2_f32) for every logit.
+ *   DDG_ATTN_BF16_FILTER  bf16 MFMA (v_mfma_f32_32x32x16_bf16) screens every logit with a rigorous
+ *                         error margin; every key that could reach the k+1 largest exact logits is
+ *                         re-scored in fp32, and only fp32 values are ranked and weighted: the kept
+ *                         sets and fills are those of fp32 arithmetic (up to fp32 summation order), at
+ *                         the bf16 matrix rate.  Larger k (radix path) always runs in fp32. */
+#define DDG_ATTN_F32 0
+#define DDG_ATTN_BF16_FILTER 1
+
 size_t ddg_attn_workspace_bytes(int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k);
 int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset,
                        const float *Xk0, const uint8_t *mk, const float *W,
                        const int32_t *offsets_host, int64_t n_query_rows, int64_t n_key_rows,
-                       int C, int D, int64_t k, float *out_code, float *out_tau, int32_t *out_nvalid,
+                       int C, int D, int64_t k, int mode, float *out_code, float *out_tau, int32_t *out_nvalid,
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* The three phases of ddg_attn_topk_fill, separately callable on the same workspace (same
@@ -261,17 +271,18 @@ int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset
  *   fill   : softmax over {s >= tau}, P^T X0, mask-merge (one more similarity pass) for the
  *            pairs select left open: the flagged ones, or all of them on the radix path
  *                                                                      (utils/util.py:463-496)
+ * k and mode must be the same in the three calls.
  * queries_alias_keys: 1 when prepare was called with identical query / key arrays. */
 int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,
                      const uint8_t *mk, const float *W, const int32_t *offsets_host,
-                     int64_t n_query_rows, int64_t n_key_rows, int C, int D,
+                     int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k, int mode,
                      void *workspace, size_t workspace_bytes, void *stream);
 int ddg_attn_select(const float *Xq0, int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k,
-                    int queries_alias_keys, float *out_code, void *workspace, size_t workspace_bytes,
-                    void *stream);
+                    int mode, int queries_alias_keys, float *out_code, void *workspace,
+                    size_t workspace_bytes, void *stream);
 int ddg_attn_fill(const int32_t *offsets_host, int64_t n_query_rows, int64_t n_key_rows, int C, int D,
-                  int64_t k, int queries_alias_keys, float *out_code, float *out_tau, int32_t *out_nvalid,
-                  void *workspace, size_t workspace_bytes, void *stream);
+                  int64_t k, int mode, int queries_alias_keys, float *out_code, float *out_tau,
+                  int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

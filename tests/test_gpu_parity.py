@@ -172,13 +172,13 @@ def test_full_sampler_against_reference(dev, name, T):
 
 
 # ----------------------------------------------------------------------------- attention fill
-def _attn_case(dev, X, W, data_m, widths, k):
+def _attn_case(dev, X, W, data_m, widths, k, mode=1):
     ops = _ops()
     lay = ops.FieldLayout(widths, dev)
     Mx = orc.expand_cols(data_m.astype(np.float32), lay.offsets)
     X0 = torch.tensor(X * Mx).to(dev)
     m8 = torch.tensor(data_m.astype(np.uint8)).to(dev)
-    out, tau, nval = ops.attn_topk_fill(X0, m8, X0, m8, torch.tensor(W).to(dev), lay, k, debug=True)
+    out, tau, nval = ops.attn_topk_fill(X0, m8, X0, m8, torch.tensor(W).to(dev), lay, k, debug=True, mode=mode)
     torch.cuda.synchronize()
     return out.cpu().numpy(), tau.cpu().numpy(), nval.cpu().numpy(), lay
 
@@ -210,16 +210,21 @@ def _check_attn(out, tau, nval, lay, X, W, data_m, k, ref_code=None):
     assert np.isnan(tau[data_m == 1]).all()
 
 
+MODES = [pytest.param(0, id="f32"), pytest.param(1, id="bf16filter")]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600"])
-def test_attn_fill_golden(dev, name):
+def test_attn_fill_golden(dev, name, mode):
     """fractional-k fixtures from the reference's init_attn_2 (k = int(N*top_k))."""
     z = load(name)
     widths = np.diff(z["offsets"]).tolist()
     k = int(z["k"])
-    out, tau, nval, lay = _attn_case(dev, z["X"], z["W"], z["data_m"], widths, k)
+    out, tau, nval, lay = _attn_case(dev, z["X"], z["W"], z["data_m"], widths, k, mode)
     _check_attn(out, tau, nval, lay, z["X"], z["W"], z["data_m"], k, ref_code=z["new_code"])
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("N,widths,k,miss", [
     (300, [1] * 20, 5, 0.3),          # register top-k (KCAP 16)
     (500, [1, 4, 1, 6, 1, 1, 3], 20, 0.4),   # register top-k (KCAP 32), categorical blocks
@@ -229,7 +234,7 @@ def test_attn_fill_golden(dev, name):
     (260, [1] * 9, 400, 0.3),         # k larger than the number of valid keys: keep all
     (130, [1, 1, 1], 3, 0.9),         # very sparse: some columns have < k or 0 valid keys
 ])
-def test_attn_fill_synthetic(dev, N, widths, k, miss):
+def test_attn_fill_synthetic(dev, N, widths, k, miss, mode):
     rng = np.random.default_rng(N + k)
     cols = []
     for w in widths:
@@ -248,11 +253,12 @@ def test_attn_fill_synthetic(dev, N, widths, k, miss):
         data_m[:, 1] = 0                      # column 1: no valid key at all -> fill 0
     off, _ = layout_of(widths)
     W = orc.expand_cols(np.abs(rng.uniform(size=(C, C))) * (1e-3 if N % 2 == 0 else 0.05), off).astype(np.float32)
-    out, tau, nval, lay = _attn_case(dev, X, W, data_m, widths, k)
+    out, tau, nval, lay = _attn_case(dev, X, W, data_m, widths, k, mode)
     _check_attn(out, tau, nval, lay, X, W, data_m, k)
 
 
-def test_attn_fill_sharded_queries(dev):
+@pytest.mark.parametrize("mode", MODES)
+def test_attn_fill_sharded_queries(dev, mode):
     """query rows = a shard of the key rows (multi-GPU layout): same result as the full call."""
     ops = _ops()
     z = load("attn_mixed257")
@@ -262,8 +268,9 @@ def test_attn_fill_sharded_queries(dev):
     X0 = torch.tensor(z["X"] * Mx).to(dev)
     m8 = torch.tensor(z["data_m"].astype(np.uint8)).to(dev)
     W = torch.tensor(z["W"]).to(dev)
-    k = int(z["k"])
-    full = ops.attn_topk_fill(X0, m8, X0, m8, W, lay, k)
+    k = int(z["k"]) if mode == 0 else 7      # 7: register path, so that mode 1 runs the bf16 screening kernel
+    full = ops.attn_topk_fill(X0, m8, X0, m8, W, lay, k, mode=mode)
     lo, hi = 100, 257
-    part = ops.attn_topk_fill(X0[lo:hi].contiguous(), m8[lo:hi].contiguous(), X0, m8, W, lay, k, q_row_offset=lo)
+    part = ops.attn_topk_fill(X0[lo:hi].contiguous(), m8[lo:hi].contiguous(), X0, m8, W, lay, k, q_row_offset=lo,
+                              mode=mode)
     assert torch.equal(part, full[lo:hi])
