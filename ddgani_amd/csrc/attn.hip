@@ -388,6 +388,14 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
 // Workgroup = 8 waves x 32 queries of one column sharing one key stream (stages of 128 keys).
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef FILT_STATS
+__device__ unsigned long long g_filt_stats[4];     // experiments only: [0] re-scored, [1] inserted, [2] subtiles with events
+extern "C" int ddg_debug_filt_stats(unsigned long long *out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_filt_stats), 32) != hipSuccess) return DDG_E_LAUNCH;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_filt_stats), z, 32) != hipSuccess) return DDG_E_LAUNCH; }
+    return DDG_OK;
+}
+#endif
 #define QPBF 256
 #define TKF 128
 #define FILT_EPS 8.0e-3f
@@ -511,6 +519,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
         const int cb = t & 1;
         if (t + 1 < nst) prefetch(t + 1);
         const int rem_stage = key_hi - key_lo - t * TKF;
+        unsigned long long cmk = 0;                  // candidate bits of the stage: 16 * sub + g
 #pragma unroll 1
         for (int sub = 0; sub < TKF / 32; ++sub) {
             const int rem = rem_stage - sub * 32;       // valid key rows in this 32-key tile
@@ -524,7 +533,10 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
                 const bf16x8 a8 = *reinterpret_cast<const bf16x8 *>(Ab + st * 32);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, breg[st], acc, 0, 0, 0);
             }
-            const float thr_adj = lst[KCAP - 1] - qe;
+            // both halves of a query screen against the larger of their two (k+1)-th values: k+1 keys of
+            // the other half at or above it already exclude anything below it from the merged list
+            const float thr_pair = fmaxf(lst[KCAP - 1], __shfl_xor(lst[KCAP - 1], 32));
+            const float thr_adj = thr_pair - qe;
             unsigned cm = 0;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -532,33 +544,54 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
                 const bool ok = (kr < rem) && (acc[g] > thr_adj);
                 cm |= ok ? (1u << g) : 0u;
             }
+            cmk |= (unsigned long long)cm << (16 * sub);
+        }
 #ifdef FILT_NO_EVENTS
-            cm = 0;
+        cmk = 0;
 #endif
-            unsigned long long bal = __ballot(cm != 0);
-            while (bal) {                                    // rare: exact fp32 re-scoring, one candidate at a time
-                const int src = __ffsll((long long)bal) - 1;
-                const unsigned cms = (unsigned)__builtin_amdgcn_readlane((int)cm, src);
-                const int g = __ffs((int)cms) - 1;
-                const int kr = sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * (src >> 5);
-                const int kidx = kidx_of(cb)[kr];
-                const int qr = __builtin_amdgcn_readlane(qrow, src);
-                const float *xq = p.Xqp + (int64_t)qr * DP + lane;
-                const float *xk = p.Xkp + (int64_t)kidx * DP + lane;
+        // candidates of the stage: exact fp32 re-scoring, four at a time so that their loads overlap
+        unsigned long long bal = __ballot(cmk != 0);
+        while (bal) {
+            int srcs[4], krs[4];
+            const float *xqp[4], *xkp[4];
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                srcs[j] = 0; krs[j] = 0;
+                int qr = 0, kidx = 0;                        // idle slots load row 0 and are ignored
+                if (bal) {                                   // wave-uniform
+                    const int src = __ffsll((long long)bal) - 1;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cmk, src);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cmk >> 32), src);
+                    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                    const int bit = __ffsll((long long)m) - 1;
+                    if (lane == src) cmk &= ~(1ull << bit);
+                    if ((m & (m - 1)) == 0) bal &= ~(1ull << src);
+                    const int g = bit & 15;
+                    const int kr = (bit >> 4) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (src >> 5);
+                    kidx = kidx_of(cb)[kr];
+                    qr = __builtin_amdgcn_readlane(qrow, src);
+                    srcs[j] = src; krs[j] = kr; n = j + 1;
+                }
+                xqp[j] = p.Xqp + (int64_t)qr * DP + lane;
+                xkp[j] = p.Xkp + (int64_t)kidx * DP + lane;
+            }
+            float xqv[4][NE], xkv[4][NE];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) { xqv[j][i] = xqp[j][64 * i]; xkv[j][i] = xkp[j][64 * i]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 float part = 0.f;
 #pragma unroll
-                for (int i = 0; i < NE; ++i) part = fmaf(wreg[i] * xq[64 * i], xk[64 * i], part);
+                for (int i = 0; i < NE; ++i) part = fmaf(wreg[i] * xqv[j][i], xkv[j][i], part);
                 const float sv = wave_sum(part);
-                if (lane == src) {
-                    cm &= ~(1u << g);
-                    if (sv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, sv, key_lo + t * TKF + kr);
-                    // logits screened against the old threshold may have dropped out: re-screen
-                    const float ta = lst[KCAP - 1] - qe;
-#pragma unroll
-                    for (int g2 = 0; g2 < 16; ++g2)
-                        if (!(acc[g2] > ta)) cm &= ~(1u << g2);
-                }
-                bal = __ballot(cm != 0);
+#ifdef FILT_STATS
+                if (j < n && lane == srcs[j]) { atomicAdd(&g_filt_stats[0], 1ull); if (sv > lst[KCAP - 1]) atomicAdd(&g_filt_stats[1], 1ull); }
+#endif
+                if (j < n && lane == srcs[j] && sv > lst[KCAP - 1])
+                    list_insert_kv<KCAP>(lst, lpos, sv, key_lo + t * TKF + krs[j]);
             }
         }
         if (t + 1 < nst) commit(cb ^ 1);
