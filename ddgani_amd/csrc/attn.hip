@@ -40,7 +40,7 @@ struct AttnArgs {
     const __bf16 *Xkh;         // [Nk][DP] bf16(Xkp) (filter kernel)
     const float *kmax;         // [1] largest key 2-norm (filter kernel)
     float *st_val;             // filter kernel: top-(k+1) lists parked between key-chunk launches,
-    int32_t *st_pos;           //   [block - blk_lo][k+1][512 threads]
+    int32_t *st_pos;           //   [block - blk_lo][k+1][FILT_NT threads]
     int key_lo, key_hi;        // key-list positions [key_lo, key_hi) streamed by this launch
     int blk_lo;                // first workgroup of this launch's group
     const int32_t *klist;      // [C][Nk]
@@ -102,8 +102,7 @@ __device__ __forceinline__ int block_column(const int32_t *qb_start, int C, int 
 // (lanes h == 0) flag a tie at the k-th logit, or softmax over the kept k entries and gather their
 // column-c values: the fill without a second similarity pass (utils/util.py:463-496).
 template <int KCAP>
-__device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP], int64_t slot,
-                                            int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h) {
+__device__ __forceinline__ void merge_halves(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP]) {
     const int ndummy = KCAP - (p.k + 1);
     float ov[KCAP];
     int op[KCAP];
@@ -114,6 +113,13 @@ __device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP
     }
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) list_insert_kv<KCAP>(lst, lpos, (i >= ndummy) ? ov[i] : -INFINITY, op[i]);
+}
+
+// lanes h == 0 hold the merged top-(k+1) list of their query
+template <int KCAP>
+__device__ __forceinline__ void topk_output(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP], int64_t slot,
+                                            int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h) {
+    const int ndummy = KCAP - (p.k + 1);
     if (h == 0 && qrow >= 0) {
         const bool tie = nk > p.k && lst[KCAP - 1] == lst[KCAP - 2];
         p.tau[slot] = (nk >= p.k) ? lst[KCAP - 2] : -INFINITY;
@@ -143,6 +149,13 @@ __device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP
             }
         }
     }
+}
+
+template <int KCAP>
+__device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP], int64_t slot,
+                                            int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h) {
+    merge_halves<KCAP>(p, lst, lpos);
+    topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
 }
 
 template <int KS4, int MODE, int KCAP>
@@ -396,8 +409,12 @@ extern "C" int ddg_debug_filt_stats(unsigned long long *out4, int reset) {
     return DDG_OK;
 }
 #endif
-#define QPBF 256
-#define TKF 128
+#ifndef FILT_NW
+#define FILT_NW 8                     // waves per workgroup of the screening kernel (4: two workgroups per CU, measured slower)
+#endif
+#define FILT_NT (64 * FILT_NW)        // threads per workgroup
+#define QPBF (32 * FILT_NW)           // queries per workgroup
+#define TKF (16 * FILT_NW)            // keys per stage
 #define FILT_EPS 8.0e-3f
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -406,14 +423,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 template <int KS, int KCAP>
-__global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
+__global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
     constexpr int DP = KS * 16;
     constexpr int RSTR = DP * 2 + 16;        // LDS row stride in bytes: conflict-free ds_read_b128
     constexpr int CPR = DP / 8;              // 16-byte chunks per key row
     constexpr int NCH = TKF * CPR;
-    constexpr int NPF = (NCH + 511) / 512;
-    constexpr int NE = DP / 64;              // fp32 elements per lane in the cooperative exact dot
+    constexpr int NPF = (NCH + FILT_NT - 1) / FILT_NT;
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     auto kbuf = [&](int b) -> char * { return fsm + b * (TKF * RSTR); };
     auto kidx_of = [&](int b) -> int * { return reinterpret_cast<int *>(fsm + 2 * TKF * RSTR) + b * TKF; };
@@ -433,8 +458,8 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
     // Infinity Cache while every workgroup of the group reads it; lists are parked in between
     const int key_lo = p.key_lo;
     const int key_hi = p.key_hi < nk ? p.key_hi : nk;
-    if (!(key_lo < nk || (nk == 0 && key_lo == 0))) return;      // column exhausted by an earlier launch
-    const bool first_chunk = key_lo == 0, last_chunk = p.key_hi >= nk;
+    if (key_lo >= nk) return;      // column exhausted by an earlier launch (or by the warm-up kernel)
+    const bool last_chunk = p.key_hi >= nk;
     const int32_t *kl = p.klist + (int64_t)c * p.Nk;
     const int off_c = p.offsets[c];
     const int d_c = p.offsets[c + 1] - off_c;
@@ -465,22 +490,18 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
     }
     qn2 += __shfl_xor(qn2, 32);
     const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
-    float wreg[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) wreg[i] = p.Wp[(int64_t)c * DP + lane + 64 * i];
-
     float lst[KCAP];
     int lpos[KCAP];
     const int ndummy = KCAP - (p.k + 1);
-    float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * 512 + tid;
-    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * 512 + tid;
+    float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) {
         lst[i] = (i < ndummy || qrow < 0) ? INFINITY : -INFINITY;   // padding slots never take candidates
         lpos[i] = -1;
-        if (!first_chunk && i >= ndummy) {
-            lst[i] = sval[(int64_t)(i - ndummy) * 512];
-            lpos[i] = spos[(int64_t)(i - ndummy) * 512];
+        if (i >= ndummy && h == 0) {
+            lst[i] = sval[(int64_t)(i - ndummy) * FILT_NT];
+            lpos[i] = spos[(int64_t)(i - ndummy) * FILT_NT];
         }
     }
 
@@ -490,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
     auto prefetch = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + 512 * i;
+            const int idx = tid + FILT_NT * i;
             const int row = idx / CPR, ch = idx - row * CPR;
             const int pos = key_lo + t * TKF + row;
             const int kidx = (idx < NCH && pos < key_hi) ? kl[pos] : -1;
@@ -502,13 +523,87 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
     auto commit = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + 512 * i;
+            const int idx = tid + FILT_NT * i;
             if (idx < NCH) {
                 const int row = idx / CPR, ch = idx - row * CPR;
                 *reinterpret_cast<uint4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
                 if (ch == 0) kidx_of(b)[row] = pfk[i];
             }
         }
+    };
+
+    // in-flight batch of exact re-scorings
+    int pn = 0, psrc0 = -1, psrc1 = -1, psrc2 = -1, psrc3 = -1;
+    int ppos = -1;
+    f32x4 pxq[KS / 4], pxk[KS / 4];
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i) { pxq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pxk[i] = pxq[i]; }
+    auto issue_batch = [&](unsigned long long &cmk, int t, int cb) {
+        const bool has = cmk != 0;
+        const int mybit = has ? __ffsll((long long)cmk) - 1 : 0;
+        const int mykr = (mybit >> 4) * 32 + (mybit & 3) + 8 * ((mybit & 15) >> 2) + 4 * h;
+        unsigned long long bal = __ballot(has);
+        int src[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            src[j] = -1;
+            if (bal) { src[j] = __ffsll((long long)bal) - 1; bal &= bal - 1; }
+        }
+        psrc0 = src[0]; psrc1 = src[1]; psrc2 = src[2]; psrc3 = src[3];
+        pn = (src[0] >= 0) + (src[1] >= 0) + (src[2] >= 0) + (src[3] >= 0);
+        const bool picked = lane == src[0] || lane == src[1] || lane == src[2] || lane == src[3];
+        ppos = -1;
+        if (picked) { cmk &= cmk - 1; ppos = key_lo + t * TKF + mykr; }
+        const int grp = lane >> 4;
+        const int sm = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
+        const int smc = sm < 0 ? 0 : sm;
+        const int kr = __shfl(mykr, smc);
+        int qr = __shfl(qrow, smc);
+        int kidx = kidx_of(cb)[kr];
+        if (sm < 0) { qr = 0; kidx = 0; }                 // idle group: loads row 0, result ignored
+        const float *xq = p.Xqp + (int64_t)qr * DP + KS * (lane & 15);
+        const float *xk = p.Xkp + (int64_t)kidx * DP + KS * (lane & 15);
+#pragma unroll
+        for (int i = 0; i < KS / 4; ++i) {
+            pxq[i] = *reinterpret_cast<const f32x4 *>(xq + 4 * i);
+            pxk[i] = *reinterpret_cast<const f32x4 *>(xk + 4 * i);
+        }
+    };
+    auto complete_batch = [&]() {
+        if (pn == 0) return;                               // wave-uniform
+        const float *wq = p.Wp + (int64_t)c * DP + KS * (lane & 15);
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < KS / 4; ++i) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part = fmaf(wv[e] * pxq[i][e], pxk[i][e], part);
+        }
+        const float sv = row16_sum(part);
+        float mysv = -INFINITY;
+        {
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 0));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 16));
+            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 32));
+            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 48));
+            if (lane == psrc0) mysv = s0;
+            if (lane == psrc1) mysv = s1;
+            if (lane == psrc2) mysv = s2;
+            if (lane == psrc3) mysv = s3;
+        }
+#ifdef FILT_STATS
+        if (mysv > -INFINITY) atomicAdd(&g_filt_stats[0], 1ull);
+        if (lane == 0) atomicAdd(&g_filt_stats[2], 1ull);
+#endif
+        const float osv = __shfl_xor(mysv, 32);
+        const int opos = __shfl_xor(ppos, 32);
+        if (__any(h == 0 && mysv > lst[KCAP - 1])) {
+            if (h == 0 && mysv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, mysv, ppos);
+        }
+        if (__any(h == 0 && osv > lst[KCAP - 1])) {
+            if (h == 0 && osv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, osv, opos);
+        }
+        pn = 0;
     };
 
     const int nst = (key_hi - key_lo + TKF - 1) / TKF;
@@ -533,10 +628,9 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
                 const bf16x8 a8 = *reinterpret_cast<const bf16x8 *>(Ab + st * 32);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, breg[st], acc, 0, 0, 0);
             }
-            // both halves of a query screen against the larger of their two (k+1)-th values: k+1 keys of
-            // the other half at or above it already exclude anything below it from the merged list
-            const float thr_pair = fmaxf(lst[KCAP - 1], __shfl_xor(lst[KCAP - 1], 32));
-            const float thr_adj = thr_pair - qe;
+            // one list per query, kept by its h == 0 lane; the h == 1 lane screens against the same threshold
+            const float thr_other = __shfl_xor(lst[KCAP - 1], 32);
+            const float thr_adj = (h ? thr_other : lst[KCAP - 1]) - qe;
             unsigned cm = 0;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -549,62 +643,146 @@ __global__ __launch_bounds__(512, 2) void k_attn_filt(AttnArgs p) {
 #ifdef FILT_NO_EVENTS
         cmk = 0;
 #endif
-        // candidates of the stage: exact fp32 re-scoring, four at a time so that their loads overlap
-        unsigned long long bal = __ballot(cmk != 0);
-        while (bal) {
-            int srcs[4], krs[4];
-            const float *xqp[4], *xkp[4];
-            int n = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                srcs[j] = 0; krs[j] = 0;
-                int qr = 0, kidx = 0;                        // idle slots load row 0 and are ignored
-                if (bal) {                                   // wave-uniform
-                    const int src = __ffsll((long long)bal) - 1;
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cmk, src);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cmk >> 32), src);
-                    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-                    const int bit = __ffsll((long long)m) - 1;
-                    if (lane == src) cmk &= ~(1ull << bit);
-                    if ((m & (m - 1)) == 0) bal &= ~(1ull << src);
-                    const int g = bit & 15;
-                    const int kr = (bit >> 4) * 32 + (g & 3) + 8 * (g >> 2) + 4 * (src >> 5);
-                    kidx = kidx_of(cb)[kr];
-                    qr = __builtin_amdgcn_readlane(qrow, src);
-                    srcs[j] = src; krs[j] = kr; n = j + 1;
-                }
-                xqp[j] = p.Xqp + (int64_t)qr * DP + lane;
-                xkp[j] = p.Xkp + (int64_t)kidx * DP + lane;
-            }
-            float xqv[4][NE], xkv[4][NE];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < NE; ++i) { xqv[j][i] = xqp[j][64 * i]; xkv[j][i] = xkp[j][64 * i]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float part = 0.f;
-#pragma unroll
-                for (int i = 0; i < NE; ++i) part = fmaf(wreg[i] * xqv[j][i], xkv[j][i], part);
-                const float sv = wave_sum(part);
-#ifdef FILT_STATS
-                if (j < n && lane == srcs[j]) { atomicAdd(&g_filt_stats[0], 1ull); if (sv > lst[KCAP - 1]) atomicAdd(&g_filt_stats[1], 1ull); }
-#endif
-                if (j < n && lane == srcs[j] && sv > lst[KCAP - 1])
-                    list_insert_kv<KCAP>(lst, lpos, sv, key_lo + t * TKF + krs[j]);
-            }
+        // Candidates: exact fp32 re-scoring, four per batch (16 lanes each), then every list takes its
+        // insertion at once.  (Leaving the last batch in flight across the next stage did not pay: the
+        // extra live registers spilled.)
+        while (__any(cmk != 0)) {
+            issue_batch(cmk, t, cb);
+            complete_batch();
         }
         if (t + 1 < nst) commit(cb ^ 1);
         __syncthreads();
     }
+    complete_batch();
     if (last_chunk) {
-        topk_finish<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
+        topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
     } else {
 #pragma unroll
         for (int i = 0; i < KCAP; ++i)
+            if (i >= ndummy && h == 0) {
+                sval[(int64_t)(i - ndummy) * FILT_NT] = lst[i];
+                spos[(int64_t)(i - ndummy) * FILT_NT] = lpos[i];
+            }
+    }
+}
+
+// Warm-up of the screening kernel: the first WARMK key-list positions in exact fp32 (fp32 MFMA, as
+// k_attn<MODE_TOPK>, same workgroup geometry as k_attn_filt).  It gives every query a threshold before
+// the bf16 stream starts, so that only about (k+1) ln(N / WARMK) + margin keys per query need the
+// exact re-scoring instead of the first few hundred.  Lists are parked for k_attn_filt (h == 0 lanes),
+// or finished right here when the column has no more than WARMK keys.
+#define WARMK 512
+template <int KS4, int KCAP>
+__global__ __launch_bounds__(FILT_NT, 2) void k_attn_warm(AttnArgs p) {
+    constexpr int DP = KS4 * 8;
+    constexpr int LSTR = DP + 4;
+    constexpr int NPF = (TK * DP / 4 + FILT_NT - 1) / FILT_NT;   // float4 per thread and 32-key tile
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    __shared__ int s_col;
+    const int nblocks = p.qb_start[p.C];
+    const int blk = p.blk_lo + (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    if (tid == 0) s_col = block_column(p.qb_start, p.C, blk);
+    __syncthreads();
+    const int c = s_col;
+    const int nk = p.nk[c];
+    const int nkw = nk < WARMK ? nk : WARMK;
+    const int32_t *kl = p.klist + (int64_t)c * p.Nk;
+    const int off_c = p.offsets[c];
+    const int d_c = p.offsets[c + 1] - off_c;
+    const int64_t slot = (int64_t)blk * QPBF + wid * 32 + r32;
+    const int qrow = p.qlist[slot];
+
+    float breg[KS4 * 4];
+    {
+        const float *wq = p.Wp + (int64_t)c * DP + 4 * h;
+        const float *xq = p.Xqp + (int64_t)(qrow < 0 ? 0 : qrow) * DP + 4 * h;
+#pragma unroll
+        for (int u = 0; u < KS4; ++u) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 8 * u);
+            f32x4 xv = *reinterpret_cast<const f32x4 *>(xq + 8 * u);
+            if (qrow < 0) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) breg[4 * u + s] = wv[s] * xv[s];
+        }
+    }
+    float lst[KCAP];
+    int lpos[KCAP];
+    const int ndummy = KCAP - (p.k + 1);
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        lst[i] = (i < ndummy || qrow < 0) ? INFINITY : -INFINITY;
+        lpos[i] = -1;
+    }
+
+    f32x4 pf[NPF];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + FILT_NT * i;
+            const int row = idx / (DP / 4), c4 = idx - row * (DP / 4);
+            const int pos = t * TK + row;
+            const int kidx = (row < TK && pos < nkw) ? kl[pos] : -1;
+            pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kidx >= 0) pf[i] = *reinterpret_cast<const f32x4 *>(p.Xkp + (int64_t)kidx * DP + c4 * 4);
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + FILT_NT * i;
+            const int row = idx / (DP / 4), c4 = idx - row * (DP / 4);
+            if (row < TK) *reinterpret_cast<f32x4 *>(buf + row * LSTR + c4 * 4) = pf[i];
+        }
+    };
+    float *kbuf0 = wsm, *kbuf1 = wsm + TK * LSTR;
+    const int ntk = (nkw + TK - 1) / TK;
+    if (ntk > 0) { prefetch(0); commit(kbuf0); }
+    __syncthreads();
+    for (int t = 0; t < ntk; ++t) {
+        float *cur = (t & 1) ? kbuf1 : kbuf0;
+        float *nxt = (t & 1) ? kbuf0 : kbuf1;
+        if (t + 1 < ntk) prefetch(t + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        const float *Ab = cur + r32 * LSTR + 4 * h;
+#pragma unroll
+        for (int u = 0; u < KS4; ++u) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Ab + 8 * u);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], breg[4 * u + s], acc, 0, 0, 0);
+        }
+        const int rem = nkw - t * TK;
+        float thr = lst[KCAP - 1];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+            float v = acc[g];
+            if (kr >= rem) v = -INFINITY;
+            if (__any(v > thr)) {
+                list_insert_kv<KCAP>(lst, lpos, v, t * TK + kr);
+                thr = lst[KCAP - 1];
+            }
+        }
+        if (t + 1 < ntk) commit(nxt);
+        __syncthreads();
+    }
+    merge_halves<KCAP>(p, lst, lpos);
+    if (nk <= WARMK) {
+        topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
+    } else if (h == 0) {
+        float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+        int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i)
             if (i >= ndummy) {
-                sval[(int64_t)(i - ndummy) * 512] = lst[i];
-                spos[(int64_t)(i - ndummy) * 512] = lpos[i];
+                sval[(int64_t)(i - ndummy) * FILT_NT] = lst[i];
+                spos[(int64_t)(i - ndummy) * FILT_NT] = lpos[i];
             }
     }
 }
@@ -861,7 +1039,7 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
     {
         const int64_t kk = k > DDG_MAX_TOPK_REG ? 0 : (k < 1 ? 1 : k) + 1;
         const int64_t grp = w.slots / QPBF + C < FILT_GROUP ? w.slots / QPBF + C : FILT_GROUP;
-        const size_t st = Nk > filt_chunk() ? (size_t)grp * 512 * kk * 4 : 0;
+        const size_t st = (size_t)grp * FILT_NT * kk * 4;
         w.st_val = (float *)take(st);
         w.st_pos = (int32_t *)take(st);
     }
@@ -902,9 +1080,11 @@ static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_byte
 template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
     const size_t lds = (size_t)2 * TKF * (KS * 32 + 16) + 2 * TKF * 4;
-    static size_t granted = 48 * 1024;
+    const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
+    static size_t granted = 48 * 1024, granted_w = 48 * 1024;
     int rc = set_lds_attr((const void *)k_attn_filt<KS, KCAP>, lds, granted);
     if (rc) return rc;
+    if ((rc = set_lds_attr((const void *)k_attn_warm<KS * 2, KCAP>, lds_w, granted_w))) return rc;
     // groups of workgroups (outer) x chunks of the key lists (inner): every launch of a group streams
     // the same chunk, so it is served from the Infinity Cache / L2 instead of HBM once per workgroup
     AttnArgs b = a;
@@ -912,10 +1092,11 @@ static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
         const int64_t gn = nblocks_max - g0 < FILT_GROUP ? nblocks_max - g0 : FILT_GROUP;
         b.blk_lo = (int)g0;
         const int64_t CH = filt_chunk();
-        for (int64_t k0 = 0; k0 == 0 || k0 < a.Nk; k0 += CH) {
+        k_attn_warm<KS * 2, KCAP><<<(unsigned)gn, FILT_NT, lds_w, s>>>(b);          // positions [0, WARMK), exact fp32
+        for (int64_t k0 = WARMK; k0 < a.Nk; k0 += CH) {
             b.key_lo = (int)k0;
             b.key_hi = (int)(k0 + CH < a.Nk ? k0 + CH : ((int64_t)1 << 31) - 1);
-            k_attn_filt<KS, KCAP><<<(unsigned)gn, 512, lds, s>>>(b);
+            k_attn_filt<KS, KCAP><<<(unsigned)gn, FILT_NT, lds, s>>>(b);
         }
     }
     DDG_CHECK_LAUNCH();
