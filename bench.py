@@ -89,7 +89,7 @@ def cpu_baseline(tab_cfg, lay_widths, k_frac_rows, T, D, N_full, sample_rows):
 
 
 def pmc_traffic(workload, rows, kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    """HBM bytes per step (summed over the kernel's launches of one step, like `achieved`) of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/rNN/pmc_traffic_<workload>_rows<N>.json: FETCH_SIZE and WRITE_SIZE collected in separate
     runs of this same command and corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read
     from inside a timed run, so the figure is attached only when workload and row count match."""
@@ -100,8 +100,8 @@ def pmc_traffic(workload, rows, kernel_prefix):
         except Exception:
             continue
         for k, v in d.get("kernels", {}).items():
-            if k.startswith(kernel_prefix) and "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v:
-                return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(f, ROOT)
+            if k.startswith(kernel_prefix) and "fetch_bytes_per_step" in v and "write_bytes_per_step" in v:
+                return v["fetch_bytes_per_step"] + v["write_bytes_per_step"], os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -217,7 +217,10 @@ def main():
                          "kernel": ("k_attn_filt (bf16 MFMA similarity screening + exact top-k + fill)" if filt else
                                     "k_attn<MODE_TOPK> (fp32 MFMA similarity + top-k + fill)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "flops_per_launch": flops, "launch_ms": sel / n_launch},
+                         "flops_per_launch": flops, "launch_ms": sel / n_launch,
+                         "launches_note": ("one 'launch' = the key-chunk x workgroup-group launches of k_attn_filt of one "
+                                           "step (plus the 512-key fp32 warm-up kernel), timed together with HIP events on "
+                                           "the launch stream") if filt else "one launch per step"},
         }
         if not a.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lay.widths, k, T, lay.D, N, a.cpu_rows)

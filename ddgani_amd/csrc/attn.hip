@@ -74,6 +74,9 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __device__ __forceinline__ int level_shift(int L) { return L < 4 ? 25 - 7 * L : 0; }
 __device__ __forceinline__ int level_bits(int L) { return L < 4 ? 7 : 4; }
 
+#ifdef FILT_STATS
+__device__ unsigned long long g_filt_stats[4];     // experiments only
+#endif
 // sorted (descending) insertion that carries the key position along with the logit
 template <int KCAP>
 __device__ __forceinline__ void list_insert_kv(float (&lst)[KCAP], int (&pos)[KCAP], float v, int q) {
@@ -129,6 +132,9 @@ __device__ __forceinline__ void topk_output(const AttnArgs &p, float (&lst)[KCAP
             if (i >= ndummy) vmax = fmaxf(vmax, lst[i]);
         p.smax[slot] = vmax;
         p.flag[slot] = tie ? 1 : 0;
+#ifdef FILT_STATS
+        if (tie && atomicAdd(&g_filt_stats[3], 1ull) < 6) printf("tie: qrow %d nk %d k %d vals %g %g %g\n", qrow, nk, p.k, lst[KCAP - 3], lst[KCAP - 2], lst[KCAP - 1]);
+#endif
         if (!tie) {
             float wgt[KCAP];
             float Zs = 0.f;
@@ -401,8 +407,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
 // Workgroup = 8 waves x 32 queries of one column sharing one key stream (stages of 128 keys).
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifdef FILT_STATS
-__device__ unsigned long long g_filt_stats[4];     // experiments only: [0] re-scored, [1] inserted, [2] subtiles with events
+#ifdef FILT_STATS   // experiments only: [0] re-scored, [2] batches, [3] tie-flagged pairs
 extern "C" int ddg_debug_filt_stats(unsigned long long *out4, int reset) {
     if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_filt_stats), 32) != hipSuccess) return DDG_E_LAUNCH;
     if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_filt_stats), z, 32) != hipSuccess) return DDG_E_LAUNCH; }
