@@ -110,7 +110,8 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
             d[value_cat] = enc.transform(d[value_cat])
         return d.values.astype(float)
     shutil.copy(src_csv, os.path.join(HERE, name + ".csv"))
-    np.savez_compressed(os.path.join(HERE, f"e2e_{name}.npz"), scores=np.array(log), armse=np.array(armse),
+    tag = name if miss_type == "MCAR" else f"{name}_{miss_type}"
+    np.savez_compressed(os.path.join(HERE, f"e2e_{tag}.npz"), miss_type=np.array(miss_type), scores=np.array(log), armse=np.array(armse),
                         amae=np.array(amae), data_m=np.asarray(data_m), corr=corr, fill_coded=coded(fill_df),
                         attn_coded=coded(attn), ori_coded=coded(ori_data), epochs=np.array(epochs),
                         categorical_cols=np.array(param["categorical_cols"], dtype=np.int64), T=np.array(param["T"]),
@@ -120,4 +121,6 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
 
 
 if __name__ == "__main__":
-    main()
+    a = sys.argv[1:]
+    main(name=a[0] if a else "hospital", epochs=int(a[1]) if len(a) > 1 else 200,
+         miss_type=a[2] if len(a) > 2 else "MCAR", miss_rate=float(a[3]) if len(a) > 3 else 0.2)

@@ -30,20 +30,21 @@ from util_golden import GOLD, load
 pytestmark = pytest.mark.gpu
 
 
-def _run_pipeline(tmp_path, epochs):
+def _run_pipeline(tmp_path, tag, csv_name):
     from ddgani_amd.BaseLine import DiffGANI
     from ddgani_amd.utils import util
     from ddgani_amd.utils.data_loader import data_loader, set_label, value_loader
-    z = load("e2e_hospital")
+    z = load(tag)
     param = json.loads(str(z["param_json"]))
-    param["epochs"] = epochs
+    param["epochs"] = int(z["epochs"])
+    miss_type = str(z["miss_type"]) if "miss_type" in z.files else "MCAR"
     path = str(tmp_path) + "/"
-    label_file, label_num = set_label(os.path.join(GOLD, "hospital.csv"), path, "True")
+    label_file, label_num = set_label(os.path.join(GOLD, csv_name), path, "True")
     miss_rate, seed = float(z["miss_rate"]), int(z["seed"])
     args = types.SimpleNamespace(UseAttention="True", UseLearner="True", UseFD="True")
     np.random.seed(0); random.seed(0); torch.manual_seed(0)
     (ori_data, miss_data, data_m, label_data, _, _, continuous_cols, nan_data, _, all_data) = data_loader(
-        label_file, miss_rate, param["categorical_cols"], "True", "MCAR", seed)
+        label_file, miss_rate, param["categorical_cols"], "True", miss_type, seed)
     values, _, value_cat = value_loader(label_file, continuous_cols, "True")
     miss_data.columns = values
     miss_data.to_csv(path + f"miss_data_{miss_rate}.csv", index=None)
@@ -67,8 +68,11 @@ def _run_pipeline(tmp_path, epochs):
     return z, data_m, attn.values.astype(float), log, final, continuous_cols, pins
 
 
-def test_hospital_end_to_end(tmp_path):
-    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, int(z_epochs()))
+@pytest.mark.parametrize("tag,csv_name", [("e2e_hospital", "hospital.csv"), ("e2e_wine_MNAR", "wine.csv")])
+def test_end_to_end(tmp_path, tag, csv_name):
+    """hospital: 9 columns, 7 categorical (one-hot heavy), MCAR 0.2, fallback validation split;
+    wine: 13 numeric columns, MNAR (BASELINE.json config 2 style), 142 rows."""
+    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, tag, csv_name)
     assert np.array_equal(np.asarray(data_m), z["data_m"])
     # attention fill: numeric cells to 1e-4 relative; categorical cells (arg-max of a softmax-weighted
     # vote) may flip only on near-ties
@@ -81,7 +85,7 @@ def test_hospital_end_to_end(tmp_path):
         rel = np.abs(attn[:, num] - ref[:, num]) / np.maximum(np.abs(ref[:, num]), 1e-6)
         assert (rel > 1e-4).mean() < 0.005, f"{(rel > 1e-4).mean():.4%} of numeric attention cells beyond 1e-4"
         assert rel.max() < 2e-3, rel.max()
-    mism = (attn[:, ~num] != ref[:, ~num]).mean()
+    mism = (attn[:, ~num] != ref[:, ~num]).mean() if (~num).any() else 0.0
     assert mism < 0.002, f"categorical attention cells differing from the reference: {mism:.4%}"
     scores = z["scores"]
     print("scores", log, "reference", scores.tolist())
@@ -93,7 +97,3 @@ def test_hospital_end_to_end(tmp_path):
     for (ep, r, m), (rr, mm) in zip(log, scores):
         assert abs(r - rr) < 2.5e-3 and abs(m - mm) < 2.5e-3, (ep, r, rr, m, mm)
     assert abs(final[0] - float(z["armse"])) < 2.5e-3 and abs(final[1] - float(z["amae"])) < 2.5e-3
-
-
-def z_epochs():
-    return load("e2e_hospital")["epochs"]
