@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Training-step throughput ("plus, separately, training steps/s"): generator +
+discriminator minibatch steps (B = 128, model/Diffusion.py:287-311 / :356-372) on a synthetic table,
+on-chip random numbers.  Prints one JSON line.  Not the headline metric (bench.py is)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--rows", type=int, default=200_000)
+    ap.add_argument("--epochs", type=int, default=50)
+    a = ap.parse_args()
+    from ddgani_amd import ops, synth
+    from ddgani_amd.model import Diffusion as D_, Discriminator_model as DM
+    dev = torch.device("cuda:0")
+    tab = synth.make_table(a.workload, dev, rows=a.rows)
+    lay, T = tab.layout, tab.T
+
+    class F:
+        def __init__(s, w): s.w = w; s.data_type = "Categorical Data" if w > 1 else "Numerical Data"
+        def dim(s): return s.w
+    torch.manual_seed(3407)
+    G = D_.Generator_x0(lay.D, 2 * lay.D, lay.D, T + 1, [F(w) for w in lay.widths]).to(dev)
+    Dn = DM.Discriminator_noise_x(2 * lay.D, lay.D // 2, lay.C, T + 1).to(dev)
+    optG = D_._NetState(G.device_params(refresh=True), ops.GEN_KEYS, 1e-4, 1e-4)
+    optD = D_._NetState(Dn.device_params(refresh=True), ops.DISC_KEYS, 1e-4, 0.0)
+    DS = D_.Diffusion_setting(T, lay.D, dev)
+    m_data = tab.m8.float()
+    lw = {"Res_weight": 100, "G_D_weight": 1, "D_weight": 0.2, "L_weight": 0.1}
+    rnd = D_.ChipRandom(0)
+
+    def epoch(e):
+        D_.train_one_epoch_Generator(G, Dn, DS, tab.x_diff, optG, None, 0.0, e, a.epochs, T, dev, None, tab.M, m_data, lw,
+                                     [], None, None, rnd=rnd)
+        D_.train_one_epoch_discriminator_noise_x(G, Dn, DS, tab.x_diff, optD, None, 0.0, e, a.epochs, T, dev, None, tab.M,
+                                                 m_data, lw, rnd=rnd)
+    for e in range(1, 4):
+        epoch(e)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e in range(1, a.epochs + 1):
+        epoch(e)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = a.epochs * 2 * T
+    print(json.dumps({"metric": "training steps/s (generator + discriminator minibatch steps, B=128)",
+                      "value": steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3,
+                      "config": {"workload": a.workload, "rows": a.rows, "encoded_dim": lay.D, "cols": lay.C, "T": T,
+                                 "epochs": a.epochs, "rng": "chip"}, "dtype": "f32", "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,9 @@ struct AttnArgs {
     float *st_val;             // filter kernel: top-(k+1) lists parked between key-chunk launches,
     int32_t *st_pos;           //   [block - blk_lo][k+1][FILT_NT threads]
     int key_lo, key_hi;        // key-list positions [key_lo, key_hi) streamed by this launch
+    int32_t *cand_pos;         // screening -> exact pass: [block - blk_lo][FILT_CAPH][FILT_NT] key-list positions
+    int32_t *cand_cnt;         //   [block - blk_lo][FILT_NT] candidates of the chunk (> FILT_CAPH = overflow)
+    int32_t *st_ovf;           //   [block - blk_lo][FILT_NT] sticky overflow marker of the pair
     int blk_lo;                // first workgroup of this launch's group
     const int32_t *klist;      // [C][Nk]
     const int32_t *nk;         // [C]
@@ -121,10 +124,11 @@ __device__ __forceinline__ void merge_halves(const AttnArgs &p, float (&lst)[KCA
 // lanes h == 0 hold the merged top-(k+1) list of their query
 template <int KCAP>
 __device__ __forceinline__ void topk_output(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP], int64_t slot,
-                                            int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h) {
+                                            int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h,
+                                            bool force_flag = false) {
     const int ndummy = KCAP - (p.k + 1);
     if (h == 0 && qrow >= 0) {
-        const bool tie = nk > p.k && lst[KCAP - 1] == lst[KCAP - 2];
+        const bool tie = force_flag || (nk > p.k && lst[KCAP - 1] == lst[KCAP - 2]);
         p.tau[slot] = (nk >= p.k) ? lst[KCAP - 2] : -INFINITY;
         float vmax = -INFINITY;
 #pragma unroll
@@ -437,8 +441,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int KS, int KCAP>
-__global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
+#define FILT_CAPH 32                  // candidate slots per (query, lane half) and key chunk
+
+// ---- screening pass over one chunk of the key lists: bf16 MFMA logits against the threshold each query
+// had when the chunk started; the key-list positions of everything that may reach the top-(k+1) are
+// appended to the lane's candidate slots.  No exact arithmetic, no lists: a pure MFMA stream.
+template <int KS>
+__global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
     constexpr int RSTR = DP * 2 + 16;        // LDS row stride in bytes: conflict-free ds_read_b128
     constexpr int CPR = DP / 8;              // 16-byte chunks per key row
@@ -446,7 +455,6 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
     constexpr int NPF = (NCH + FILT_NT - 1) / FILT_NT;
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     auto kbuf = [&](int b) -> char * { return fsm + b * (TKF * RSTR); };
-    auto kidx_of = [&](int b) -> int * { return reinterpret_cast<int *>(fsm + 2 * TKF * RSTR) + b * TKF; };
     __shared__ int s_col;
 
     const int nblocks = p.qb_start[p.C];
@@ -459,15 +467,10 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
     __syncthreads();
     const int c = s_col;
     const int nk = p.nk[c];
-    // this launch streams key-list positions [key_lo, key_hi): a chunk small enough to stay in the
-    // Infinity Cache while every workgroup of the group reads it; lists are parked in between
     const int key_lo = p.key_lo;
     const int key_hi = p.key_hi < nk ? p.key_hi : nk;
-    if (key_lo >= nk) return;      // column exhausted by an earlier launch (or by the warm-up kernel)
-    const bool last_chunk = p.key_hi >= nk;
+    if (key_lo >= nk) return;                 // column exhausted by an earlier chunk (or by the warm-up kernel)
     const int32_t *kl = p.klist + (int64_t)c * p.Nk;
-    const int off_c = p.offsets[c];
-    const int d_c = p.offsets[c + 1] - off_c;
     const int64_t slot = (int64_t)blk * QPBF + wid * 32 + r32;
     const int qrow = p.qlist[slot];
 
@@ -495,131 +498,43 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
     }
     qn2 += __shfl_xor(qn2, 32);
     const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
-    float lst[KCAP];
-    int lpos[KCAP];
-    const int ndummy = KCAP - (p.k + 1);
-    float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
-    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
-#pragma unroll
-    for (int i = 0; i < KCAP; ++i) {
-        lst[i] = (i < ndummy || qrow < 0) ? INFINITY : -INFINITY;   // padding slots never take candidates
-        lpos[i] = -1;
-        if (i >= ndummy && h == 0) {
-            lst[i] = sval[(int64_t)(i - ndummy) * FILT_NT];
-            lpos[i] = spos[(int64_t)(i - ndummy) * FILT_NT];
-        }
-    }
+    // threshold = the query's exact (k+1)-th largest logit so far (parked by its h == 0 lane)
+    const float thr = p.st_val[((int64_t)blockIdx.x * (p.k + 1) + p.k) * FILT_NT + (tid & ~32)];
+    const float thr_adj = (qrow < 0) ? INFINITY : thr - qe;
+    int32_t *cand = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + tid;
+    int ncand = 0;
 
-    // key staging: 16-byte chunks of bf16 rows gathered through klist
-    uint4 pf[NPF];
-    int pfk[NPF];
-    auto prefetch = [&](int t) {
+    // key staging with a prefetch distance of two stages: the loads of stage t+2 are issued before
+    // stage t is computed and committed to LDS at the end of stage t+1 (Infinity-Cache / HBM latency is
+    // longer than one stage of MFMAs)
+    uint4 pfE[NPF], pfO[NPF];
+    auto prefetch = [&](int t, uint4 (&pf)[NPF]) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + FILT_NT * i;
             const int row = idx / CPR, ch = idx - row * CPR;
             const int pos = key_lo + t * TKF + row;
             const int kidx = (idx < NCH && pos < key_hi) ? kl[pos] : -1;
-            pfk[i] = kidx;
             pf[i] = uint4{0u, 0u, 0u, 0u};
             if (kidx >= 0) pf[i] = *reinterpret_cast<const uint4 *>(p.Xkh + (int64_t)kidx * DP + ch * 8);
         }
     };
-    auto commit = [&](int b) {
+    auto commit = [&](int b, const uint4 (&pf)[NPF]) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + FILT_NT * i;
             if (idx < NCH) {
                 const int row = idx / CPR, ch = idx - row * CPR;
                 *reinterpret_cast<uint4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
-                if (ch == 0) kidx_of(b)[row] = pfk[i];
             }
         }
     };
 
-    // in-flight batch of exact re-scorings
-    int pn = 0, psrc0 = -1, psrc1 = -1, psrc2 = -1, psrc3 = -1;
-    int ppos = -1;
-    f32x4 pxq[KS / 4], pxk[KS / 4];
-#pragma unroll
-    for (int i = 0; i < KS / 4; ++i) { pxq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pxk[i] = pxq[i]; }
-    auto issue_batch = [&](unsigned long long &cmk, int t, int cb) {
-        const bool has = cmk != 0;
-        const int mybit = has ? __ffsll((long long)cmk) - 1 : 0;
-        const int mykr = (mybit >> 4) * 32 + (mybit & 3) + 8 * ((mybit & 15) >> 2) + 4 * h;
-        unsigned long long bal = __ballot(has);
-        int src[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            src[j] = -1;
-            if (bal) { src[j] = __ffsll((long long)bal) - 1; bal &= bal - 1; }
-        }
-        psrc0 = src[0]; psrc1 = src[1]; psrc2 = src[2]; psrc3 = src[3];
-        pn = (src[0] >= 0) + (src[1] >= 0) + (src[2] >= 0) + (src[3] >= 0);
-        const bool picked = lane == src[0] || lane == src[1] || lane == src[2] || lane == src[3];
-        ppos = -1;
-        if (picked) { cmk &= cmk - 1; ppos = key_lo + t * TKF + mykr; }
-        const int grp = lane >> 4;
-        const int sm = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
-        const int smc = sm < 0 ? 0 : sm;
-        const int kr = __shfl(mykr, smc);
-        int qr = __shfl(qrow, smc);
-        int kidx = kidx_of(cb)[kr];
-        if (sm < 0) { qr = 0; kidx = 0; }                 // idle group: loads row 0, result ignored
-        const float *xq = p.Xqp + (int64_t)qr * DP + KS * (lane & 15);
-        const float *xk = p.Xkp + (int64_t)kidx * DP + KS * (lane & 15);
-#pragma unroll
-        for (int i = 0; i < KS / 4; ++i) {
-            pxq[i] = *reinterpret_cast<const f32x4 *>(xq + 4 * i);
-            pxk[i] = *reinterpret_cast<const f32x4 *>(xk + 4 * i);
-        }
-    };
-    auto complete_batch = [&]() {
-        if (pn == 0) return;                               // wave-uniform
-        const float *wq = p.Wp + (int64_t)c * DP + KS * (lane & 15);
-        float part = 0.f;
-#pragma unroll
-        for (int i = 0; i < KS / 4; ++i) {
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 4 * i);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) part = fmaf(wv[e] * pxq[i][e], pxk[i][e], part);
-        }
-        const float sv = row16_sum(part);
-        float mysv = -INFINITY;
-        {
-            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 0));
-            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 16));
-            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 32));
-            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 48));
-            if (lane == psrc0) mysv = s0;
-            if (lane == psrc1) mysv = s1;
-            if (lane == psrc2) mysv = s2;
-            if (lane == psrc3) mysv = s3;
-        }
-#ifdef FILT_STATS
-        if (mysv > -INFINITY) atomicAdd(&g_filt_stats[0], 1ull);
-        if (lane == 0) atomicAdd(&g_filt_stats[2], 1ull);
-#endif
-        const float osv = __shfl_xor(mysv, 32);
-        const int opos = __shfl_xor(ppos, 32);
-        if (__any(h == 0 && mysv > lst[KCAP - 1])) {
-            if (h == 0 && mysv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, mysv, ppos);
-        }
-        if (__any(h == 0 && osv > lst[KCAP - 1])) {
-            if (h == 0 && osv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, osv, opos);
-        }
-        pn = 0;
-    };
-
     const int nst = (key_hi - key_lo + TKF - 1) / TKF;
-    if (nst > 0) { prefetch(0); commit(0); }
-    __syncthreads();
-
-    for (int t = 0; t < nst; ++t) {
+    auto stage_iter = [&](int t, uint4 (&pf_load)[NPF], const uint4 (&pf_commit)[NPF]) {
         const int cb = t & 1;
-        if (t + 1 < nst) prefetch(t + 1);
+        if (t + 2 < nst) prefetch(t + 2, pf_load);
         const int rem_stage = key_hi - key_lo - t * TKF;
-        unsigned long long cmk = 0;                  // candidate bits of the stage: 16 * sub + g
 #pragma unroll 1
         for (int sub = 0; sub < TKF / 32; ++sub) {
             const int rem = rem_stage - sub * 32;       // valid key rows in this 32-key tile
@@ -628,14 +543,15 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[g] = 0.f;
             const char *Ab = kbuf(cb) + (sub * 32 + r32) * RSTR + h * 16;
+            // all A fragments of the tile are requested before the first MFMA: one LDS latency per tile
+            // instead of one per MFMA (the compiler otherwise recycles two fragment registers)
+            bf16x8 afr[KS];
 #pragma unroll
-            for (int st = 0; st < KS; ++st) {
-                const bf16x8 a8 = *reinterpret_cast<const bf16x8 *>(Ab + st * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, breg[st], acc, 0, 0, 0);
-            }
-            // one list per query, kept by its h == 0 lane; the h == 1 lane screens against the same threshold
-            const float thr_other = __shfl_xor(lst[KCAP - 1], 32);
-            const float thr_adj = (h ? thr_other : lst[KCAP - 1]) - qe;
+            for (int st = 0; st < KS; ++st) afr[st] = *reinterpret_cast<const bf16x8 *>(Ab + st * 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < KS; ++st)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st], breg[st], acc, 0, 0, 0);
             unsigned cm = 0;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -643,31 +559,145 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_filt(AttnArgs p) {
                 const bool ok = (kr < rem) && (acc[g] > thr_adj);
                 cm |= ok ? (1u << g) : 0u;
             }
-            cmk |= (unsigned long long)cm << (16 * sub);
-        }
-#ifdef FILT_NO_EVENTS
-        cmk = 0;
-#endif
-        // Candidates: exact fp32 re-scoring, four per batch (16 lanes each), then every list takes its
-        // insertion at once.  (Leaving the last batch in flight across the next stage did not pay: the
-        // extra live registers spilled.)
-        while (__any(cmk != 0)) {
-            issue_batch(cmk, t, cb);
-            complete_batch();
-        }
-        if (t + 1 < nst) commit(cb ^ 1);
-        __syncthreads();
-    }
-    complete_batch();
-    if (last_chunk) {
-        topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
-    } else {
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i)
-            if (i >= ndummy && h == 0) {
-                sval[(int64_t)(i - ndummy) * FILT_NT] = lst[i];
-                spos[(int64_t)(i - ndummy) * FILT_NT] = lpos[i];
+            while (cm) {                                 // rare: remember the candidate's key-list position
+                const int g = __ffs((int)cm) - 1;
+                cm &= cm - 1;
+                const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = key_lo + t * TKF + sub * 32 + kr;
+                ++ncand;
             }
+        }
+        if (t + 1 < nst) commit(cb ^ 1, pf_commit);
+        __syncthreads();
+    };
+    if (nst > 0) { prefetch(0, pfE); commit(0, pfE); }
+    if (nst > 1) prefetch(1, pfO);
+    __syncthreads();
+    for (int t = 0; t < nst; t += 2) {
+        stage_iter(t, pfE, pfO);
+        if (t + 1 < nst) stage_iter(t + 1, pfO, pfE);
+    }
+    p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
+}
+
+// ---- exact pass over the candidates of one chunk: every candidate is re-scored in fp32 (16 lanes per
+// candidate, four candidates per wave instruction stream) and offered to the query's top-(k+1) list.
+// No key stream and no workgroup barrier: waves only wait for their own gathers.
+template <int KS, int KCAP>
+__global__ __launch_bounds__(FILT_NT, 2) void k_attn_rescore(AttnArgs p) {
+    constexpr int DP = KS * 16;
+    __shared__ int s_col;
+    const int nblocks = p.qb_start[p.C];
+    const int blk = p.blk_lo + (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    if (tid == 0) s_col = block_column(p.qb_start, p.C, blk);
+    __syncthreads();
+    const int c = s_col;
+    const int nk = p.nk[c];
+    if (p.key_lo >= nk) return;
+    const bool last_chunk = p.key_hi >= nk;
+    const int32_t *kl = p.klist + (int64_t)c * p.Nk;
+    const int off_c = p.offsets[c];
+    const int d_c = p.offsets[c + 1] - off_c;
+    const int64_t slot = (int64_t)blk * QPBF + wid * 32 + r32;
+    const int qrow = p.qlist[slot];
+
+    float lst[KCAP];
+    int lpos[KCAP];
+    const int ndummy = KCAP - (p.k + 1);
+    float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        lst[i] = INFINITY;
+        lpos[i] = -1;
+        if (i >= ndummy && h == 0) {
+            lst[i] = sval[(int64_t)(i - ndummy) * FILT_NT];
+            lpos[i] = spos[(int64_t)(i - ndummy) * FILT_NT];
+        }
+    }
+    int32_t *ovfp = p.st_ovf + (int64_t)blockIdx.x * FILT_NT + tid;
+    const int32_t *cand = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + tid;
+    int ncand = qrow < 0 ? 0 : p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid];
+    int ovf = *ovfp;
+    if (ncand > FILT_CAPH) { ovf = 1; ncand = FILT_CAPH; }
+    ovf |= __shfl_xor(ovf, 32);
+
+    const float *wq = p.Wp + (int64_t)c * DP + KS * (lane & 15);
+    f32x4 wreg[KS / 4];
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i) wreg[i] = *reinterpret_cast<const f32x4 *>(wq + 4 * i);
+
+    for (int r = 0; __any(r < ncand); ++r) {
+        const bool has = r < ncand;
+        const int mypos = has ? cand[(int64_t)r * FILT_NT] : 0;
+        const int mykidx = has ? kl[mypos] : 0;
+        float mysv = -INFINITY;
+        unsigned long long bal = __ballot(has);
+        while (bal) {
+            int src[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                src[j] = -1;
+                if (bal) { src[j] = __ffsll((long long)bal) - 1; bal &= bal - 1; }
+            }
+            const int grp = lane >> 4;
+            const int sm = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
+            const int smc = sm < 0 ? 0 : sm;
+            int kidx = __shfl(mykidx, smc);
+            int qr = __shfl(qrow, smc);
+            if (sm < 0) { qr = 0; kidx = 0; }             // idle group: loads row 0, result ignored
+            const float *xq = p.Xqp + (int64_t)qr * DP + KS * (lane & 15);
+            const float *xk = p.Xkp + (int64_t)kidx * DP + KS * (lane & 15);
+            f32x4 xqv[KS / 4], xkv[KS / 4];
+#pragma unroll
+            for (int i = 0; i < KS / 4; ++i) {
+                xqv[i] = *reinterpret_cast<const f32x4 *>(xq + 4 * i);
+                xkv[i] = *reinterpret_cast<const f32x4 *>(xk + 4 * i);
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < KS / 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = fmaf(wreg[i][e] * xqv[i][e], xkv[i][e], part);
+            const float sv = row16_sum(part);
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 0));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 16));
+            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 32));
+            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 48));
+            if (lane == src[0]) mysv = s0;
+            if (lane == src[1]) mysv = s1;
+            if (lane == src[2]) mysv = s2;
+            if (lane == src[3]) mysv = s3;
+        }
+#ifdef FILT_STATS
+        if (has) atomicAdd(&g_filt_stats[0], 1ull);
+        if (lane == 0) atomicAdd(&g_filt_stats[2], 1ull);
+#endif
+        const float osv = __shfl_xor(mysv, 32);
+        const int opos = __shfl_xor(mypos, 32);
+        if (__any(h == 0 && mysv > lst[KCAP - 1])) {
+            if (h == 0 && mysv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, mysv, mypos);
+        }
+        if (__any(h == 0 && osv > lst[KCAP - 1])) {
+            if (h == 0 && osv > lst[KCAP - 1]) list_insert_kv<KCAP>(lst, lpos, osv, opos);
+        }
+    }
+    if (last_chunk) {
+        topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h, ovf != 0);
+    } else {
+        if (h == 0) {
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i)
+                if (i >= ndummy) {
+                    sval[(int64_t)(i - ndummy) * FILT_NT] = lst[i];
+                    spos[(int64_t)(i - ndummy) * FILT_NT] = lpos[i];
+                }
+        }
+        *ovfp = ovf;
     }
 }
 
@@ -780,7 +810,10 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_warm(AttnArgs p) {
     merge_halves<KCAP>(p, lst, lpos);
     if (nk <= WARMK) {
         topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
-    } else if (h == 0) {
+    } else {
+        p.st_ovf[(int64_t)blockIdx.x * FILT_NT + tid] = 0;
+    }
+    if (nk > WARMK && h == 0) {
         float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
         int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
 #pragma unroll
@@ -989,23 +1022,25 @@ struct AttnWs {
     int32_t *flags;            // [0] = 1 when queries alias keys (set by prepare); [1] = bits of max key norm
     PairList L1;               // primary list (128 or 256 pairs per workgroup, by mode)
     PairList L2, L3;           // fallback lists (128 per workgroup)
-    float *st_val;             // parked lists of the filter kernel, FILT_GROUP workgroups
-    int32_t *st_pos;
+    float *st_val;             // parked lists of the screening path, FILT_GROUP workgroups
+    int32_t *st_pos, *cand_pos, *cand_cnt, *st_ovf;
     size_t total;
     int64_t slots;             // capacity of every per-pair array
     int nchunk_k, nchunk_q;
 };
 
 #define FILT_GROUP 16384       // workgroups per launch group of the filter kernel (bounds the parked state)
-// key-list positions per launch: the keys (fp32 + bf16 rows) of a chunk stay in the Infinity Cache.
-// DDG_FILT_CHUNK (multiple of 128) overrides it: tests use a small value to cover the chunked path.
-static int64_t filt_chunk() {
-    static int64_t v = 0;
-    if (v == 0) {
+// Key chunks of the screening path: [WARMK, 2 WARMK), then doubling up to FILT_CHUNK_MAX positions.  A
+// chunk is screened against the thresholds the queries had when it started, so a chunk as long as the
+// prefix before it yields about k+1 candidates per query; the cap keeps a chunk's bf16 rows inside the
+// Infinity Cache.  DDG_FILT_CHUNK (multiple of 128) forces a fixed chunk length: tests use a small one.
+#define FILT_CHUNK_MAX 262144
+static int64_t filt_chunk_fixed() {
+    static int64_t v = -1;
+    if (v < 0) {
         const char *e = getenv("DDG_FILT_CHUNK");
-        int64_t c = e ? atoll(e) : 65536;
-        if (c < 128) c = 128;
-        v = (c / 128) * 128;
+        int64_t c = e ? atoll(e) : 0;
+        v = c <= 0 ? 0 : (c < 128 ? 128 : (c / 128) * 128);
     }
     return v;
 }
@@ -1047,6 +1082,9 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
         const size_t st = (size_t)grp * FILT_NT * kk * 4;
         w.st_val = (float *)take(st);
         w.st_pos = (int32_t *)take(st);
+        w.cand_pos = (int32_t *)take(kk ? (size_t)grp * FILT_CAPH * FILT_NT * 4 : 0);
+        w.cand_cnt = (int32_t *)take(kk ? (size_t)grp * FILT_NT * 4 : 0);
+        w.st_ovf = (int32_t *)take(kk ? (size_t)grp * FILT_NT * 4 : 0);
     }
     w.total = o;
 }
@@ -1084,24 +1122,27 @@ static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_byte
 
 template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
-    const size_t lds = (size_t)2 * TKF * (KS * 32 + 16) + 2 * TKF * 4;
+    const size_t lds = (size_t)2 * TKF * (KS * 32 + 16);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
     static size_t granted = 48 * 1024, granted_w = 48 * 1024;
-    int rc = set_lds_attr((const void *)k_attn_filt<KS, KCAP>, lds, granted);
+    int rc = set_lds_attr((const void *)k_attn_screen<KS>, lds, granted);
     if (rc) return rc;
     if ((rc = set_lds_attr((const void *)k_attn_warm<KS * 2, KCAP>, lds_w, granted_w))) return rc;
-    // groups of workgroups (outer) x chunks of the key lists (inner): every launch of a group streams
-    // the same chunk, so it is served from the Infinity Cache / L2 instead of HBM once per workgroup
+    // groups of workgroups (outer, bounds the parked state) x key chunks (inner).  Per chunk: the bf16
+    // screening pass, then the exact fp32 pass over its candidates.
     AttnArgs b = a;
+    const int64_t fixed = filt_chunk_fixed();
     for (int64_t g0 = 0; g0 < nblocks_max; g0 += FILT_GROUP) {
         const int64_t gn = nblocks_max - g0 < FILT_GROUP ? nblocks_max - g0 : FILT_GROUP;
         b.blk_lo = (int)g0;
-        const int64_t CH = filt_chunk();
+        b.key_lo = 0; b.key_hi = WARMK;
         k_attn_warm<KS * 2, KCAP><<<(unsigned)gn, FILT_NT, lds_w, s>>>(b);          // positions [0, WARMK), exact fp32
-        for (int64_t k0 = WARMK; k0 < a.Nk; k0 += CH) {
+        int64_t len = fixed ? fixed : WARMK;
+        for (int64_t k0 = WARMK; k0 < a.Nk; k0 += len, len = fixed ? fixed : (2 * len < FILT_CHUNK_MAX ? 2 * len : FILT_CHUNK_MAX)) {
             b.key_lo = (int)k0;
-            b.key_hi = (int)(k0 + CH < a.Nk ? k0 + CH : ((int64_t)1 << 31) - 1);
-            k_attn_filt<KS, KCAP><<<(unsigned)gn, FILT_NT, lds, s>>>(b);
+            b.key_hi = (int)(k0 + len < a.Nk ? k0 + len : ((int64_t)1 << 31) - 1);
+            k_attn_screen<KS><<<(unsigned)gn, FILT_NT, lds, s>>>(b);
+            k_attn_rescore<KS, KCAP><<<(unsigned)gn, FILT_NT, 0, s>>>(b);
         }
     }
     DDG_CHECK_LAUNCH();
@@ -1166,7 +1207,7 @@ static inline int64_t blocks_max(const AttnWs &w, int C, int qpb) { return w.slo
 
 static void attn_args(AttnArgs &a, const AttnWs &w, const PairList &l, int64_t Nk, int C, int D, int k) {
     a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.Xkh = w.Xkh; a.kmax = reinterpret_cast<const float *>(w.flags + 1);
-    a.st_val = w.st_val; a.st_pos = w.st_pos; a.key_lo = 0; a.key_hi = 0x7fffffff; a.blk_lo = 0;
+    a.st_val = w.st_val; a.st_pos = w.st_pos; a.cand_pos = w.cand_pos; a.cand_cnt = w.cand_cnt; a.st_ovf = w.st_ovf; a.key_lo = 0; a.key_hi = 0x7fffffff; a.blk_lo = 0;
     a.klist = w.klist; a.nk = w.nk; a.qlist = l.qlist; a.qb_start = l.qb_start; a.offsets = w.offsets;
     a.tau = l.tau; a.smax = l.smax; a.flag = l.flag; a.prefix = w.prefix; a.rank = w.rank;
     a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
