@@ -504,36 +504,51 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     int32_t *cand = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + tid;
     int ncand = 0;
 
-    // key staging with a prefetch distance of two stages: the loads of stage t+2 are issued before
-    // stage t is computed and committed to LDS at the end of stage t+1 (Infinity-Cache / HBM latency is
-    // longer than one stage of MFMAs)
-    uint4 pfE[NPF], pfO[NPF];
-    auto prefetch = [&](int t, uint4 (&pf)[NPF]) {
+    // key staging: the key-list indices of stage t+2 and the key rows of stage t+1 are in flight while
+    // stage t is computed, so neither the index -> row dependence nor the Infinity-Cache / HBM latency
+    // is ever waited for inside a stage.  Rows past the end of the chunk re-read its last key (no branch,
+    // no zero fill); the epilogue ignores them through `rem`.
+    static_assert(NCH % FILT_NT == 0, "key stage must divide evenly over the workgroup");
+    int kix[NPF];
+    uint4 pf[NPF];
+    auto load_idx = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int row = (tid + FILT_NT * i) / CPR;
+            const int pos = key_lo + t * TKF + row;
+            kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = tid + FILT_NT * i;
+            const int ch = idx - (idx / CPR) * CPR;
+            pf[i] = *reinterpret_cast<const uint4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
+        }
+    };
+    auto commit = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + FILT_NT * i;
             const int row = idx / CPR, ch = idx - row * CPR;
-            const int pos = key_lo + t * TKF + row;
-            const int kidx = (idx < NCH && pos < key_hi) ? kl[pos] : -1;
-            pf[i] = uint4{0u, 0u, 0u, 0u};
-            if (kidx >= 0) pf[i] = *reinterpret_cast<const uint4 *>(p.Xkh + (int64_t)kidx * DP + ch * 8);
-        }
-    };
-    auto commit = [&](int b, const uint4 (&pf)[NPF]) {
-#pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + FILT_NT * i;
-            if (idx < NCH) {
-                const int row = idx / CPR, ch = idx - row * CPR;
-                *reinterpret_cast<uint4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
-            }
+            *reinterpret_cast<uint4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
         }
     };
 
     const int nst = (key_hi - key_lo + TKF - 1) / TKF;
-    auto stage_iter = [&](int t, uint4 (&pf_load)[NPF], const uint4 (&pf_commit)[NPF]) {
+    load_idx(0);
+    load_rows();
+    if (nst > 1) load_idx(1);
+    commit(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nst; ++t) {
         const int cb = t & 1;
-        if (t + 2 < nst) prefetch(t + 2, pf_load);
+        if (t + 1 < nst) {
+            load_rows();
+            if (t + 2 < nst) load_idx(t + 2);
+        }
         const int rem_stage = key_hi - key_lo - t * TKF;
 #pragma unroll 1
         for (int sub = 0; sub < TKF / 32; ++sub) {
@@ -552,30 +567,29 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
 #pragma unroll
             for (int st = 0; st < KS; ++st)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st], breg[st], acc, 0, 0, 0);
-            unsigned cm = 0;
+            // common case: nothing in the lane's 16 logits reaches the threshold -- eight max3 and one compare
+            float mx = fmaxf(acc[0], acc[1]);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
-                const bool ok = (kr < rem) && (acc[g] > thr_adj);
-                cm |= ok ? (1u << g) : 0u;
-            }
-            while (cm) {                                 // rare: remember the candidate's key-list position
-                const int g = __ffs((int)cm) - 1;
-                cm &= cm - 1;
-                const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = key_lo + t * TKF + sub * 32 + kr;
-                ++ncand;
+            for (int g = 2; g < 16; g += 2) mx = fmaxf(fmaxf(mx, acc[g]), acc[g + 1]);
+            if (mx > thr_adj) {
+                unsigned cm = 0;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                    const bool ok = (kr < rem) && (acc[g] > thr_adj);
+                    cm |= ok ? (1u << g) : 0u;
+                }
+                while (cm) {                             // remember the candidate's key-list position
+                    const int g = __ffs((int)cm) - 1;
+                    cm &= cm - 1;
+                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = key_lo + t * TKF + sub * 32 + kr;
+                    ++ncand;
+                }
             }
         }
-        if (t + 1 < nst) commit(cb ^ 1, pf_commit);
+        if (t + 1 < nst) commit(cb ^ 1);
         __syncthreads();
-    };
-    if (nst > 0) { prefetch(0, pfE); commit(0, pfE); }
-    if (nst > 1) prefetch(1, pfO);
-    __syncthreads();
-    for (int t = 0; t < nst; t += 2) {
-        stage_iter(t, pfE, pfO);
-        if (t + 1 < nst) stage_iter(t + 1, pfO, pfE);
     }
     p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
 }
