@@ -446,6 +446,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // ---- screening pass over one chunk of the key lists: bf16 MFMA logits against the threshold each query
 // had when the chunk started; the key-list positions of everything that may reach the top-(k+1) are
 // appended to the lane's candidate slots.  No exact arithmetic, no lists: a pure MFMA stream.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int KS>
 __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     // no zero fill); the epilogue ignores them through `rem`.
     static_assert(NCH % FILT_NT == 0, "key stage must divide evenly over the workgroup");
     int kix[NPF];
-    uint4 pf[NPF];
+    u32x4 pf[NPF];
     auto load_idx = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + FILT_NT * i;
             const int ch = idx - (idx / CPR) * CPR;
-            pf[i] = *reinterpret_cast<const uint4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
+            pf[i] = *reinterpret_cast<const u32x4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
         }
     };
     auto commit = [&](int b) {
@@ -532,63 +533,102 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         for (int i = 0; i < NPF; ++i) {
             const int idx = tid + FILT_NT * i;
             const int row = idx / CPR, ch = idx - row * CPR;
-            *reinterpret_cast<uint4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
+            *reinterpret_cast<u32x4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
         }
     };
 
+    // the rare path of one 32-key tile: which of the lane's 16 logits reach the threshold
+    auto collect = [&](const f32x16 &acc, int tile_pos, int rem) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (acc[g] > thr_adj && kr < rem) {
+                if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = tile_pos + kr;
+                ++ncand;
+            }
+        }
+    };
+
+    // One stage = TKF / 32 tiles, software-pipelined by hand in half tiles of H MFMAs.  Every MFMA slot
+    // carries the ds_read of the fragment that the slot H positions later consumes, plus one filler: a
+    // global load of the next stage (tile 0), a max3 of the previous tile's logits (second halves), or
+    // a ds_write of the commit (last tile).  sched_barrier keeps the slots as written.  Two accumulator
+    // sets alternate, so a tile's threshold test runs one tile late, beside the next tile's MFMAs.
+    constexpr int H = KS / 2;
+    constexpr int NT_STAGE = TKF / 32;
+    static_assert(NPF == H, "one staging element per MFMA slot of a half tile");
     const int nst = (key_hi - key_lo + TKF - 1) / TKF;
     load_idx(0);
     load_rows();
-    if (nst > 1) load_idx(1);
+    load_idx(1);
     commit(0);
     __syncthreads();
+    const int lds_lane = r32 * RSTR + h * 16;
 #pragma unroll 1
     for (int t = 0; t < nst; ++t) {
         const int cb = t & 1;
-        if (t + 1 < nst) {
-            load_rows();
-            if (t + 2 < nst) load_idx(t + 2);
-        }
-        const int rem_stage = key_hi - key_lo - t * TKF;
-#pragma unroll 1
-        for (int sub = 0; sub < TKF / 32; ++sub) {
-            const int rem = rem_stage - sub * 32;       // valid key rows in this 32-key tile
-            if (rem <= 0) break;
-            f32x16 acc;
+        const char *base = kbuf(cb) + lds_lane;
+        const int stage_pos = key_lo + t * TKF;
+        const int rem_stage = key_hi - stage_pos;
+        bf16x8 fr[2][H];
+        f32x16 cacc[2];
+        float mx[2];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-            const char *Ab = kbuf(cb) + (sub * 32 + r32) * RSTR + h * 16;
-            // all A fragments of the tile are requested before the first MFMA: one LDS latency per tile
-            // instead of one per MFMA (the compiler otherwise recycles two fragment registers)
-            bf16x8 afr[KS];
+        for (int i = 0; i < H; ++i) fr[0][i] = *reinterpret_cast<const bf16x8 *>(base + i * 32);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int st = 0; st < KS; ++st) afr[st] = *reinterpret_cast<const bf16x8 *>(Ab + st * 32);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < NT_STAGE; ++s) {
 #pragma unroll
-            for (int st = 0; st < KS; ++st)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[st], breg[st], acc, 0, 0, 0);
-            // common case: nothing in the lane's 16 logits reaches the threshold -- eight max3 and one compare
-            float mx = fmaxf(acc[0], acc[1]);
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * s + u;
 #pragma unroll
-            for (int g = 2; g < 16; g += 2) mx = fmaxf(fmaxf(mx, acc[g]), acc[g + 1]);
-            if (mx > thr_adj) {
-                unsigned cm = 0;
+                for (int i = 0; i < H; ++i) {
+                    if (u == 0 && i == 0) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
-                    const bool ok = (kr < rem) && (acc[g] > thr_adj);
-                    cm |= ok ? (1u << g) : 0u;
-                }
-                while (cm) {                             // remember the candidate's key-list position
-                    const int g = __ffs((int)cm) - 1;
-                    cm &= cm - 1;
-                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
-                    if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = key_lo + t * TKF + sub * 32 + kr;
-                    ++ncand;
+                        for (int g = 0; g < 16; ++g) cacc[s & 1][g] = 0.f;
+                    }
+                    cacc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[u * H + i], cacc[s & 1], 0, 0, 0);
+                    if (j + 1 < 2 * NT_STAGE)
+                        fr[(j + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(base + ((j + 1) >> 1) * 32 * RSTR + (((j + 1) & 1) * H + i) * 32);
+                    if (s == 0 && u == 0) {              // rows of stage t+1 (indices arrived a stage ago)
+                        const int idx = tid + FILT_NT * i;
+                        const int ch = idx - (idx / CPR) * CPR;
+                        pf[i] = *reinterpret_cast<const u32x4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
+                    }
+                    if (s == 0 && u == 1) {              // indices of stage t+2
+                        const int row = (tid + FILT_NT * i) / CPR;
+                        const int pos = stage_pos + 2 * TKF + row;
+                        kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
+                    }
+                    if (s > 0 && u == 1) {               // previous tile's row maximum, 8 ops over H slots
+                        const f32x16 &pa = cacc[(s - 1) & 1];
+#pragma unroll
+                        for (int o = 0; o < 8; ++o)
+                            if (o * H / 8 == i)
+                                mx[(s - 1) & 1] = (o == 0) ? fmaxf(pa[0], pa[1]) : fmaxf(fmaxf(mx[(s - 1) & 1], pa[2 * o]), pa[2 * o + 1]);
+                    }
+                    if (s == NT_STAGE - 1 && u == 1) {   // commit stage t+1 to the other buffer
+                        const int idx = tid + FILT_NT * i;
+                        const int row = idx / CPR, ch = idx - row * CPR;
+                        *reinterpret_cast<u32x4 *>(kbuf(cb ^ 1) + row * RSTR + ch * 16) = pf[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (s > 0) {
+                if (__builtin_amdgcn_ballot_w64(mx[(s - 1) & 1] > thr_adj) != 0)
+                    collect(cacc[(s - 1) & 1], stage_pos + (s - 1) * 32, rem_stage - (s - 1) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (t + 1 < nst) commit(cb ^ 1);
+        {
+            const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
+            float m = fmaxf(pa[0], pa[1]);
+#pragma unroll
+            for (int g = 2; g < 16; g += 2) m = fmaxf(fmaxf(m, pa[g]), pa[g + 1]);
+            if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0)
+                collect(pa, stage_pos + (NT_STAGE - 1) * 32, rem_stage - (NT_STAGE - 1) * 32);
+        }
         __syncthreads();
     }
     p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
