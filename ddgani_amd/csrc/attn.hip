@@ -77,6 +77,15 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __device__ __forceinline__ int level_shift(int L) { return L < 4 ? 25 - 7 * L : 0; }
 __device__ __forceinline__ int level_bits(int L) { return L < 4 ? 7 : 4; }
 
+#ifdef FILT_TIMING
+__device__ unsigned long long g_filt_time[8];      // experiments only: s_memtime sums per wave of k_attn_screen
+extern "C" int ddg_debug_filt_time(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_filt_time), 64) != hipSuccess) return DDG_E_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_filt_time), z, 64) != hipSuccess) return DDG_E_LAUNCH; }
+    return DDG_OK;
+}
+#define TSTAMP() __builtin_amdgcn_s_memtime()
+#endif
 #ifdef FILT_STATS
 __device__ unsigned long long g_filt_stats[4];     // experiments only
 #endif
@@ -441,6 +450,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ void set_wave_prio(int pr) {      // s_setprio takes an immediate
+    switch (pr) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#ifndef FILT_PRIO
+#define FILT_PRIO(s) (3 - ((s) & 3))
+#endif
 #define FILT_CAPH 32                  // candidate slots per (query, lane half) and key chunk
 
 // ---- screening pass over one chunk of the key lists: bf16 MFMA logits against the threshold each query
@@ -537,15 +557,27 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         }
     };
 
-    // the rare path of one 32-key tile: which of the lane's 16 logits reach the threshold
+    // the not-so-rare path of one 32-key tile (about one tile in five at 1M rows): which of the lane's 16
+    // logits reach the threshold.  Branch-free bit mask (the per-g branches of a naive version cost several
+    // hundred cycles a call, and a stage waits for its slowest wave); only lanes with a hit enter the loop.
     auto collect = [&](const f32x16 &acc, int tile_pos, int rem) {
+#ifdef FILT_NOCOLLECT      // timing experiments only (wrong results): what this path costs
+        ++ncand; return;
+#endif
+        unsigned cm = 0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
-            if (acc[g] > thr_adj && kr < rem) {
-                if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = tile_pos + kr;
-                ++ncand;
-            }
+        for (int g = 0; g < 16; ++g) cm |= (acc[g] > thr_adj) ? (1u << g) : 0u;
+        if (rem < 32) {                                  // last tile of the chunk: drop the padding rows
+            unsigned vm = 0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) vm |= ((g & 3) + 8 * (g >> 2) + 4 * h < rem) ? (1u << g) : 0u;
+            cm &= vm;
+        }
+        while (cm) {
+            const int g = __ffs((int)cm) - 1;
+            cm &= cm - 1;
+            if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = tile_pos + (g & 3) + 8 * (g >> 2) + 4 * h;
+            ++ncand;
         }
     };
 
@@ -564,6 +596,9 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     commit(0);
     __syncthreads();
     const int lds_lane = r32 * RSTR + h * 16;
+#ifdef FILT_TIMING
+    unsigned long long tm_tiles = 0, tm_tail = 0, tm_bar = 0, tm_coll = 0, ts0 = TSTAMP(), ts_begin = ts0;
+#endif
 #pragma unroll 1
     for (int t = 0; t < nst; ++t) {
         const int cb = t & 1;
@@ -578,6 +613,11 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NT_STAGE; ++s) {
+            // The SIMD's arbiter favours its oldest wave, and a dependent MFMA chain is always ready: left
+            // alone, one wave of the pair runs its whole stage first and then idles at the barrier while
+            // its partner runs alone.  Priority falls with the tile index, so the wave that is behind
+            // owns the matrix pipe and the pair alternates tile by tile.
+            set_wave_prio(FILT_PRIO(s));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = 2 * s + u;
@@ -616,11 +656,18 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 }
             }
             if (s > 0) {
-                if (__builtin_amdgcn_ballot_w64(mx[(s - 1) & 1] > thr_adj) != 0)
+                if (__builtin_amdgcn_ballot_w64(mx[(s - 1) & 1] > thr_adj) != 0) {
+#ifdef FILT_TIMING
+                    ++tm_coll;
+#endif
                     collect(cacc[(s - 1) & 1], stage_pos + (s - 1) * 32, rem_stage - (s - 1) * 32);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#ifdef FILT_TIMING
+        const unsigned long long ts1 = TSTAMP();
+#endif
         {
             const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
             float m = fmaxf(pa[0], pa[1]);
@@ -629,8 +676,21 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
             if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0)
                 collect(pa, stage_pos + (NT_STAGE - 1) * 32, rem_stage - (NT_STAGE - 1) * 32);
         }
+#ifdef FILT_TIMING
+        const unsigned long long ts2 = TSTAMP();
         __syncthreads();
+        const unsigned long long ts3 = TSTAMP();
+        tm_tiles += ts1 - ts0; tm_tail += ts2 - ts1; tm_bar += ts3 - ts2; ts0 = ts3;
+#else
+        __syncthreads();
+#endif
     }
+#ifdef FILT_TIMING
+    if (lane == 0) {
+        atomicAdd(&g_filt_time[0], tm_tiles); atomicAdd(&g_filt_time[1], tm_tail); atomicAdd(&g_filt_time[2], tm_bar);
+        atomicAdd(&g_filt_time[3], (unsigned long long)nst); atomicAdd(&g_filt_time[4], TSTAMP() - ts_begin); atomicAdd(&g_filt_time[5], tm_coll);
+    }
+#endif
     p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
 }
 
