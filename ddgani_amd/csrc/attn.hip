@@ -467,15 +467,18 @@ __device__ __forceinline__ void set_wave_prio(int pr) {      // s_setprio takes 
 // had when the chunk started; the key-list positions of everything that may reach the top-(k+1) are
 // appended to the lane's candidate slots.  No exact arithmetic, no lists: a pure MFMA stream.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
+__host__ __device__ constexpr int screen_stage_keys(int KS) { return KS <= 12 ? 128 : 64; }
 template <int KS>
 __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
     constexpr int RSTR = DP * 2 + 16;        // LDS row stride in bytes: conflict-free ds_read_b128
     constexpr int CPR = DP / 8;              // 16-byte chunks per key row
-    constexpr int NCH = TKF * CPR;
-    constexpr int NPF = (NCH + FILT_NT - 1) / FILT_NT;
+    constexpr int TKS = screen_stage_keys(KS);   // keys per stage
+    constexpr int NCH = TKS * CPR;
+    constexpr int NPF = NCH / FILT_NT;
     extern __shared__ __attribute__((aligned(16))) char fsm[];
-    auto kbuf = [&](int b) -> char * { return fsm + b * (TKF * RSTR); };
+    auto kbuf = [&](int b) -> char * { return fsm + b * (TKS * RSTR); };      // three stage buffers
     __shared__ int s_col;
 
     const int nblocks = p.qb_start[p.C];
@@ -525,10 +528,11 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     int32_t *cand = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + tid;
     int ncand = 0;
 
-    // key staging: the key-list indices of stage t+2 and the key rows of stage t+1 are in flight while
-    // stage t is computed, so neither the index -> row dependence nor the Infinity-Cache / HBM latency
-    // is ever waited for inside a stage.  Rows past the end of the chunk re-read its last key (no branch,
-    // no zero fill); the epilogue ignores them through `rem`.
+    // key staging, three LDS stage buffers: while stage t is computed the rows of stage t+1 are written to
+    // their buffer, the rows of stage t+2 are in flight to registers and the key-list indices of stage
+    // t+3 are in flight too, so neither the index -> row dependence nor the Infinity-Cache / HBM latency
+    // is waited for.  Rows past the end of the chunk re-read its last key (no branch, no zero fill); the
+    // candidate collection ignores them through `rem`.
     static_assert(NCH % FILT_NT == 0, "key stage must divide evenly over the workgroup");
     int kix[NPF];
     u32x4 pf[NPF];
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int row = (tid + FILT_NT * i) / CPR;
-            const int pos = key_lo + t * TKF + row;
+            const int pos = key_lo + t * TKS + row;
             kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
         }
     };
@@ -581,42 +585,52 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         }
     };
 
-    // One stage = TKF / 32 tiles, software-pipelined by hand in half tiles of H MFMAs.  Every MFMA slot
-    // carries the ds_read of the fragment that the slot H positions later consumes, plus one filler: a
-    // global load of the next stage (tile 0), a max3 of the previous tile's logits (second halves), or
-    // a ds_write of the commit (last tile).  sched_barrier keeps the slots as written.  Two accumulator
-    // sets alternate, so a tile's threshold test runs one tile late, beside the next tile's MFMAs.
+    // The key stream is one unbroken software pipeline of half tiles (H MFMAs each), written out by hand.
+    // Every MFMA slot carries the ds_read of the fragment that the slot H positions later consumes -- at
+    // the end of a stage that is already the first fragment of the next stage's buffer -- plus one filler:
+    // an LDS write of the next stage's rows, a global load of the stage after (rows, then key-list
+    // indices), or a max3 of the previous tile's logits.  sched_barrier keeps the slots as written.  Two
+    // accumulator sets alternate, so a tile's threshold test runs one tile late, beside the next tile's
+    // MFMAs.  One workgroup barrier per stage, between the writes of buffer t+1 and its first read; no
+    // wait precedes it: LDS operations of a wave complete in order and the fragment reads consumed since
+    // the writes are younger than them.  Three buffers make the write of stage t+1 safe without a second
+    // barrier: its buffer was last read in stage t-2, which every wave left before the barrier of t-1.
     constexpr int H = KS / 2;
-    constexpr int NT_STAGE = TKF / 32;
-    static_assert(NPF == H, "one staging element per MFMA slot of a half tile");
-    const int nst = (key_hi - key_lo + TKF - 1) / TKF;
+    constexpr int NT_STAGE = TKS / 32;
+    static_assert(NPF <= H && NT_STAGE >= 2 && NT_STAGE % 2 == 0, "slot plan");
+    const int nst = (key_hi - key_lo + TKS - 1) / TKS;
     load_idx(0);
     load_rows();
     load_idx(1);
     commit(0);
+    load_rows();
+    load_idx(2);
     __syncthreads();
     const int lds_lane = r32 * RSTR + h * 16;
+    bf16x8 fr[2][H];
+    f32x16 cacc[2];
+    float mx[2] = {0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { cacc[0][g] = 0.f; cacc[1][g] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < H; ++i) fr[0][i] = *reinterpret_cast<const bf16x8 *>(kbuf(0) + lds_lane + i * 32);
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef FILT_TIMING
-    unsigned long long tm_tiles = 0, tm_tail = 0, tm_bar = 0, tm_coll = 0, ts0 = TSTAMP(), ts_begin = ts0;
+    unsigned long long tm_bar = 0, tm_coll = 0, ts_begin = TSTAMP();
 #endif
+    int b_cur = 0, b_nxt = 1;
 #pragma unroll 1
     for (int t = 0; t < nst; ++t) {
-        const int cb = t & 1;
-        const char *base = kbuf(cb) + lds_lane;
-        const int stage_pos = key_lo + t * TKF;
+        const char *base = kbuf(b_cur) + lds_lane;
+        const char *base_n = kbuf(b_nxt) + lds_lane;
+        char *wr_n = kbuf(b_nxt);
+        const int stage_pos = key_lo + t * TKS;
         const int rem_stage = key_hi - stage_pos;
-        bf16x8 fr[2][H];
-        f32x16 cacc[2];
-        float mx[2];
-#pragma unroll
-        for (int i = 0; i < H; ++i) fr[0][i] = *reinterpret_cast<const bf16x8 *>(base + i * 32);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NT_STAGE; ++s) {
             // The SIMD's arbiter favours its oldest wave, and a dependent MFMA chain is always ready: left
-            // alone, one wave of the pair runs its whole stage first and then idles at the barrier while
-            // its partner runs alone.  Priority falls with the tile index, so the wave that is behind
-            // owns the matrix pipe and the pair alternates tile by tile.
+            // alone, one wave of the pair runs ahead and then idles at the barrier while its partner runs
+            // alone.  Priority falls with the tile index, so the wave that is behind owns the matrix pipe.
             set_wave_prio(FILT_PRIO(s));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -630,65 +644,70 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     cacc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[u * H + i], cacc[s & 1], 0, 0, 0);
                     if (j + 1 < 2 * NT_STAGE)
                         fr[(j + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(base + ((j + 1) >> 1) * 32 * RSTR + (((j + 1) & 1) * H + i) * 32);
-                    if (s == 0 && u == 0) {              // rows of stage t+1 (indices arrived a stage ago)
+                    else
+                        fr[0][i] = *reinterpret_cast<const bf16x8 *>(base_n + i * 32);
+                    if (j == 0 && i < NPF) {             // rows of stage t+1 (in registers since stage t-1) -> LDS
+                        const int idx = tid + FILT_NT * i;
+                        const int row = idx / CPR, ch = idx - row * CPR;
+                        *reinterpret_cast<u32x4 *>(wr_n + row * RSTR + ch * 16) = pf[i];
+                    }
+                    if (j == 1 && i < NPF) {             // rows of stage t+2 (indices arrived a stage ago)
                         const int idx = tid + FILT_NT * i;
                         const int ch = idx - (idx / CPR) * CPR;
                         pf[i] = *reinterpret_cast<const u32x4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
                     }
-                    if (s == 0 && u == 1) {              // indices of stage t+2
+                    if (j == 2 && i < NPF) {             // indices of stage t+3
                         const int row = (tid + FILT_NT * i) / CPR;
-                        const int pos = stage_pos + 2 * TKF + row;
+                        const int pos = stage_pos + 3 * TKS + row;
                         kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
                     }
-                    if (s > 0 && u == 1) {               // previous tile's row maximum, 8 ops over H slots
-                        const f32x16 &pa = cacc[(s - 1) & 1];
+                    if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
+                        const f32x16 &pa = cacc[(s + 1) & 1];
 #pragma unroll
                         for (int o = 0; o < 8; ++o)
                             if (o * H / 8 == i)
-                                mx[(s - 1) & 1] = (o == 0) ? fmaxf(pa[0], pa[1]) : fmaxf(fmaxf(mx[(s - 1) & 1], pa[2 * o]), pa[2 * o + 1]);
-                    }
-                    if (s == NT_STAGE - 1 && u == 1) {   // commit stage t+1 to the other buffer
-                        const int idx = tid + FILT_NT * i;
-                        const int row = idx / CPR, ch = idx - row * CPR;
-                        *reinterpret_cast<u32x4 *>(kbuf(cb ^ 1) + row * RSTR + ch * 16) = pf[i];
+                                mx[(s + 1) & 1] = (o == 0) ? fmaxf(pa[0], pa[1]) : fmaxf(fmaxf(mx[(s + 1) & 1], pa[2 * o]), pa[2 * o + 1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (j == 2 * NT_STAGE - 2) {             // buffer t+1 complete in every wave before its first read
+#ifdef FILT_TIMING
+                    const unsigned long long tb0 = TSTAMP();
+                    asm volatile("s_barrier" ::: "memory");
+                    tm_bar += TSTAMP() - tb0;
+#else
+                    asm volatile("s_barrier" ::: "memory");
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (s > 0) {
-                if (__builtin_amdgcn_ballot_w64(mx[(s - 1) & 1] > thr_adj) != 0) {
+            if (s > 0 || t > 0) {                        // the tile before this one (s == 0: the previous stage's last)
+                if (__builtin_amdgcn_ballot_w64(mx[(s + 1) & 1] > thr_adj) != 0) {
 #ifdef FILT_TIMING
                     ++tm_coll;
 #endif
-                    collect(cacc[(s - 1) & 1], stage_pos + (s - 1) * 32, rem_stage - (s - 1) * 32);
+                    collect(cacc[(s + 1) & 1], stage_pos + (s - 1) * 32, rem_stage - (s - 1) * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#ifdef FILT_TIMING
-        const unsigned long long ts1 = TSTAMP();
-#endif
-        {
-            const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
-            float m = fmaxf(pa[0], pa[1]);
+        const int b_old = b_cur;
+        b_cur = b_nxt;
+        b_nxt = 3 - b_old - b_nxt;
+    }
+    set_wave_prio(0);
+    {                                                    // last tile of the chunk
+        const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
+        float m = fmaxf(pa[0], pa[1]);
 #pragma unroll
-            for (int g = 2; g < 16; g += 2) m = fmaxf(fmaxf(m, pa[g]), pa[g + 1]);
-            if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0)
-                collect(pa, stage_pos + (NT_STAGE - 1) * 32, rem_stage - (NT_STAGE - 1) * 32);
-        }
-#ifdef FILT_TIMING
-        const unsigned long long ts2 = TSTAMP();
-        __syncthreads();
-        const unsigned long long ts3 = TSTAMP();
-        tm_tiles += ts1 - ts0; tm_tail += ts2 - ts1; tm_bar += ts3 - ts2; ts0 = ts3;
-#else
-        __syncthreads();
-#endif
+        for (int g = 2; g < 16; g += 2) m = fmaxf(fmaxf(m, pa[g]), pa[g + 1]);
+        if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0)
+            collect(pa, key_lo + nst * TKS - 32, key_hi - (key_lo + nst * TKS - 32));
     }
 #ifdef FILT_TIMING
     if (lane == 0) {
-        atomicAdd(&g_filt_time[0], tm_tiles); atomicAdd(&g_filt_time[1], tm_tail); atomicAdd(&g_filt_time[2], tm_bar);
-        atomicAdd(&g_filt_time[3], (unsigned long long)nst); atomicAdd(&g_filt_time[4], TSTAMP() - ts_begin); atomicAdd(&g_filt_time[5], tm_coll);
+        atomicAdd(&g_filt_time[2], tm_bar); atomicAdd(&g_filt_time[3], (unsigned long long)nst);
+        atomicAdd(&g_filt_time[4], TSTAMP() - ts_begin); atomicAdd(&g_filt_time[5], tm_coll);
     }
 #endif
     p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
@@ -1236,7 +1255,7 @@ static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_byte
 
 template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
-    const size_t lds = (size_t)2 * TKF * (KS * 32 + 16);
+    const size_t lds = (size_t)3 * screen_stage_keys(KS) * (KS * 32 + 16);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
     static size_t granted = 48 * 1024, granted_w = 48 * 1024;
     int rc = set_lds_attr((const void *)k_attn_screen<KS>, lds, granted);
