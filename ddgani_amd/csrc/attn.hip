@@ -34,6 +34,11 @@
 #define HSTRIDE 129
 
 enum { MODE_TOPK = 0, MODE_HIST = 1, MODE_FILL = 2 };
+// The register path tracks the k+2 largest logits of a pair: the k kept ones, the (k+1)-th that decides
+// whether the k-th is tied, and the (k+2)-th that tells a two-way tie (both kept, resolved on the spot)
+// from a longer one (left to the threshold pass).
+#define NLIST(k) ((k) + 2)
+static_assert(NLIST(DDG_MAX_TOPK_REG) <= 32, "register lists hold at most 32 entries");
 
 struct AttnArgs {
     const float *Xkp, *Xqp, *Wp;
@@ -118,7 +123,7 @@ __device__ __forceinline__ int block_column(const int32_t *qb_start, int C, int 
 // column-c values: the fill without a second similarity pass (utils/util.py:463-496).
 template <int KCAP>
 __device__ __forceinline__ void merge_halves(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP]) {
-    const int ndummy = KCAP - (p.k + 1);
+    const int ndummy = KCAP - NLIST(p.k);
     float ov[KCAP];
     int op[KCAP];
 #pragma unroll
@@ -130,30 +135,35 @@ __device__ __forceinline__ void merge_halves(const AttnArgs &p, float (&lst)[KCA
     for (int i = 0; i < KCAP; ++i) list_insert_kv<KCAP>(lst, lpos, (i >= ndummy) ? ov[i] : -INFINITY, op[i]);
 }
 
-// lanes h == 0 hold the merged top-(k+1) list of their query
+// lanes h == 0 hold the merged top-(k+2) list of their query: lst[KCAP-3] is the k-th largest logit (tau),
+// lst[KCAP-2] the (k+1)-th, lst[KCAP-1] the (k+2)-th.  The reference keeps every key whose probability
+// reaches the k-th largest (utils/util.py:470-476), so a key tied with the k-th is kept as well.
 template <int KCAP>
 __device__ __forceinline__ void topk_output(const AttnArgs &p, float (&lst)[KCAP], int (&lpos)[KCAP], int64_t slot,
                                             int qrow, int nk, const int32_t *kl, int off_c, int d_c, int DP, int h,
                                             bool force_flag = false) {
-    const int ndummy = KCAP - (p.k + 1);
+    const int ndummy = KCAP - NLIST(p.k);
     if (h == 0 && qrow >= 0) {
-        const bool tie = force_flag || (nk > p.k && lst[KCAP - 1] == lst[KCAP - 2]);
-        p.tau[slot] = (nk >= p.k) ? lst[KCAP - 2] : -INFINITY;
+        const bool tie = nk > p.k && lst[KCAP - 3] == lst[KCAP - 2];
+        // a longer tie may go on past the end of the list
+        const bool open = force_flag || (tie && nk > p.k + 1 && lst[KCAP - 2] == lst[KCAP - 1]);
+        const int last = tie ? KCAP - 2 : KCAP - 3;             // last kept entry
+        p.tau[slot] = (nk >= p.k) ? lst[KCAP - 3] : -INFINITY;
         float vmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < KCAP - 1; ++i)
-            if (i >= ndummy) vmax = fmaxf(vmax, lst[i]);
+            if (i >= ndummy && i <= last) vmax = fmaxf(vmax, lst[i]);
         p.smax[slot] = vmax;
-        p.flag[slot] = tie ? 1 : 0;
+        p.flag[slot] = open ? 1 : 0;
 #ifdef FILT_STATS
-        if (tie && atomicAdd(&g_filt_stats[3], 1ull) < 6) printf("tie: qrow %d nk %d k %d vals %g %g %g\n", qrow, nk, p.k, lst[KCAP - 3], lst[KCAP - 2], lst[KCAP - 1]);
+        if (open && atomicAdd(&g_filt_stats[3], 1ull) < 6) printf("tie: qrow %d nk %d k %d vals %g %g %g\n", qrow, nk, p.k, lst[KCAP - 3], lst[KCAP - 2], lst[KCAP - 1]);
 #endif
-        if (!tie) {
+        if (!open) {
             float wgt[KCAP];
             float Zs = 0.f;
 #pragma unroll
             for (int i = 0; i < KCAP - 1; ++i) {
-                const bool kept = i >= ndummy && lpos[i] >= 0;
+                const bool kept = i >= ndummy && i <= last && lpos[i] >= 0;
                 wgt[i] = kept ? expf(lst[i] - vmax) : 0.f;
                 Zs += wgt[i];
                 lpos[i] = kept ? kl[lpos[i]] : -1;      // key position -> key row
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     uint32_t prefix = 0;
     bool active = true;
     if constexpr (MODE == MODE_TOPK) {
-        const int ndummy = KCAP - (p.k + 1);
+        const int ndummy = KCAP - NLIST(p.k);
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) {
             lst[i] = (i < ndummy) ? INFINITY : -INFINITY;
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     qn2 += __shfl_xor(qn2, 32);
     const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
     // threshold = the query's exact (k+1)-th largest logit so far (parked by its h == 0 lane)
-    const float thr = p.st_val[((int64_t)blockIdx.x * (p.k + 1) + p.k) * FILT_NT + (tid & ~32)];
+    const float thr = p.st_val[((int64_t)blockIdx.x * NLIST(p.k) + NLIST(p.k) - 1) * FILT_NT + (tid & ~32)];
     const float thr_adj = (qrow < 0) ? INFINITY : thr - qe;
     int32_t *cand = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + tid;
     int ncand = 0;
@@ -740,9 +750,9 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_rescore(AttnArgs p) {
 
     float lst[KCAP];
     int lpos[KCAP];
-    const int ndummy = KCAP - (p.k + 1);
-    float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
-    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+    const int ndummy = KCAP - NLIST(p.k);
+    float *sval = p.st_val + ((int64_t)blockIdx.x * NLIST(p.k)) * FILT_NT + tid;
+    int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * NLIST(p.k)) * FILT_NT + tid;
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) {
         lst[i] = INFINITY;
@@ -879,7 +889,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_warm(AttnArgs p) {
     }
     float lst[KCAP];
     int lpos[KCAP];
-    const int ndummy = KCAP - (p.k + 1);
+    const int ndummy = KCAP - NLIST(p.k);
 #pragma unroll
     for (int i = 0; i < KCAP; ++i) {
         lst[i] = (i < ndummy || qrow < 0) ? INFINITY : -INFINITY;
@@ -947,8 +957,8 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_warm(AttnArgs p) {
         p.st_ovf[(int64_t)blockIdx.x * FILT_NT + tid] = 0;
     }
     if (nk > WARMK && h == 0) {
-        float *sval = p.st_val + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
-        int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * (p.k + 1)) * FILT_NT + tid;
+        float *sval = p.st_val + ((int64_t)blockIdx.x * NLIST(p.k)) * FILT_NT + tid;
+        int32_t *spos = p.st_pos + ((int64_t)blockIdx.x * NLIST(p.k)) * FILT_NT + tid;
 #pragma unroll
         for (int i = 0; i < KCAP; ++i)
             if (i >= ndummy) {
@@ -1210,7 +1220,7 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
         l->cnt = (int32_t *)take((size_t)2 * C * 4);
     }
     {
-        const int64_t kk = k > DDG_MAX_TOPK_REG ? 0 : (k < 1 ? 1 : k) + 1;
+        const int64_t kk = k > DDG_MAX_TOPK_REG ? 0 : NLIST(k < 1 ? 1 : k);
         const int64_t grp = w.slots / QPBF + C < FILT_GROUP ? w.slots / QPBF + C : FILT_GROUP;
         const size_t st = (size_t)grp * FILT_NT * kk * 4;
         w.st_val = (float *)take(st);
@@ -1286,10 +1296,10 @@ template <int KS4>
 static int run_select(AttnArgs &a, int64_t nb, int mode, hipStream_t s) {
     int rc;
     if (a.k <= DDG_MAX_TOPK_REG && mode == DDG_ATTN_BF16_FILTER) {
-        if (a.k < 16) return launch_filt<KS4 / 2, 16>(a, nb, s);
+        if (NLIST(a.k) <= 16) return launch_filt<KS4 / 2, 16>(a, nb, s);
         return launch_filt<KS4 / 2, 32>(a, nb, s);
     }
-    if (a.k < 16) return launch_attn<KS4, MODE_TOPK, 16>(a, nb, 0, s);
+    if (NLIST(a.k) <= 16) return launch_attn<KS4, MODE_TOPK, 16>(a, nb, 0, s);
     if (a.k <= DDG_MAX_TOPK_REG) return launch_attn<KS4, MODE_TOPK, 32>(a, nb, 0, s);
     for (int L = 0; L < 5; ++L) {
         a.level = L;

@@ -379,7 +379,7 @@ class AttnPlan:
                                      _stream()), "ddg_attn_prepare")
 
     def select(self, out=None):
-        """one similarity pass; k <= 31 also fills every pair without a tie at the k-th logit"""
+        """one similarity pass; k <= 30 also fills every pair without a three-way tie at the k-th logit"""
         if out is None:
             out = torch.empty_like(self.Xq0)
         self.out = out
@@ -389,7 +389,7 @@ class AttnPlan:
         return out
 
     def fill(self, debug: bool = False):
-        """the pairs select() left open (tie-flagged, or all of them when k > 31)"""
+        """the pairs select() left open (tie-flagged, or all of them when k > 30)"""
         tau = nval = None
         if debug:
             tau = torch.full((self.Nq, self.layout.C), float("nan"), dtype=torch.float32, device=self.out.device)

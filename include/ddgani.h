@@ -37,7 +37,7 @@ extern "C" {
 #define DDG_E_LAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch             */
 
 #define DDG_MAX_D 256         /* widest encoded table the attention kernels are built for   */
-#define DDG_MAX_TOPK_REG 31   /* absolute k up to this uses the in-register selection       */
+#define DDG_MAX_TOPK_REG 30   /* absolute k up to this uses the in-register selection       */
 
 /* library / error helpers */
 int ddg_version(void);
@@ -236,8 +236,9 @@ int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads
  * (q_row_offset = global index of its first row); keys are all rows (after the all-gather
  * in the multi-GPU case).  On one GPU pass the same pointers for queries and keys.
  * mq/mk: uint8 0/1 [rows,C].  W: [C,D].  offsets: int32[C+1] on the HOST here.
- * k >= 1.  k <= DDG_MAX_TOPK_REG selects AND fills in registers (one similarity pass; pairs with
- * an exact tie at the k-th logit take a second one); larger k uses an exact 5-level radix select
+ * k >= 1.  k <= DDG_MAX_TOPK_REG selects AND fills in registers (one similarity pass; a two-way
+ * tie at the k-th logit keeps both keys right there, pairs with a longer exact tie take a second
+ * pass); larger k uses an exact 5-level radix select
  * on the logits (5 similarity passes + a fill pass).
  * Optional debug outputs (NULL to skip): out_tau [Nq,C] (NaN where mq==1, -inf when all
  * valid keys are kept), out_nvalid int32 [Nq,C].
@@ -245,7 +246,7 @@ int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads
 /* mode: how the similarity of the register path (k <= DDG_MAX_TOPK_REG) is evaluated.
  *   DDG_ATTN_F32          fp32 MFMA (v_mfma_f32_32x32x2_f32) for every logit.
  *   DDG_ATTN_BF16_FILTER  bf16 MFMA (v_mfma_f32_32x32x16_bf16) screens every logit with a rigorous
- *                         error margin; every key that could reach the k+1 largest exact logits is
+ *                         error margin; every key that could reach the k+2 largest exact logits is
  *                         re-scored in fp32, and only fp32 values are ranked and weighted: the kept
  *                         sets and fills are those of fp32 arithmetic (up to fp32 summation order), at
  *                         the bf16 matrix rate.  Larger k (radix path) always runs in fp32. */
@@ -263,10 +264,11 @@ int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset
  * reference lines; used to time the phases and, multi-GPU, to prepare once per all-gather):
  *   prepare: padded operands + per-column key / query index lists      (utils/util.py:439-448)
  *   select : out_code <- Xq0, then ONE similarity pass                 (utils/util.py:452-466)
- *            k <= DDG_MAX_TOPK_REG: the k+1 largest logits and their key rows are kept in
- *            registers; every pair whose k-th and (k+1)-th logits differ is filled right there
- *            (softmax over the kept k, gather of the key values: utils/util.py:484-496), pairs
- *            with a tie at the k-th logit are flagged for the fill phase;
+ *            k <= DDG_MAX_TOPK_REG: the k+2 largest logits and their key rows are kept in
+ *            registers; every pair whose k-th and (k+1)-th logits differ, or tie while the
+ *            (k+2)-th is smaller, is filled right there (softmax over the kept k or k+1, gather
+ *            of the key values: utils/util.py:484-496); pairs whose tie at the k-th logit may
+ *            run past the list are flagged for the fill phase;
  *            larger k: exact 5-level radix select of tau (5 similarity passes)
  *   fill   : softmax over {s >= tau}, P^T X0, mask-merge (one more similarity pass) for the
  *            pairs select left open: the flagged ones, or all of them on the radix path

@@ -233,6 +233,10 @@ def test_attn_fill_golden(dev, name, mode):
     (300, [8] * 30, 7, 0.2),          # D = 240 one-hot heavy, massive ties
     (260, [1] * 9, 400, 0.3),         # k larger than the number of valid keys: keep all
     (130, [1, 1, 1], 3, 0.9),         # very sparse: some columns have < k or 0 valid keys
+    (350, [1] * 12, 14, 0.3),         # largest k whose k+2 list fits 16 registers
+    (350, [1] * 12, 15, 0.3),         # smallest k on the 32-register lists
+    (350, [1] * 12, 30, 0.3),         # DDG_MAX_TOPK_REG
+    (350, [1] * 12, 31, 0.3),         # first k on the radix path
 ])
 def test_attn_fill_synthetic(dev, N, widths, k, miss, mode):
     rng = np.random.default_rng(N + k)
@@ -253,6 +257,26 @@ def test_attn_fill_synthetic(dev, N, widths, k, miss, mode):
         data_m[:, 1] = 0                      # column 1: no valid key at all -> fill 0
     off, _ = layout_of(widths)
     W = orc.expand_cols(np.abs(rng.uniform(size=(C, C))) * (1e-3 if N % 2 == 0 else 0.05), off).astype(np.float32)
+    out, tau, nval, lay = _attn_case(dev, X, W, data_m, widths, k, mode)
+    _check_attn(out, tau, nval, lay, X, W, data_m, k)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [1, 4, 9])
+def test_attn_fill_duplicate_keys(dev, mode, k):
+    """exact ties at the k-th logit from duplicated rows: two-way ties are resolved inside the register
+    path (both keys kept, as utils/util.py:470-476 keeps every probability >= the k-th), three-way ties
+    go through the threshold pass; all must agree with the closed form bit-for-set."""
+    rng = np.random.default_rng(77 + k)
+    base = rng.normal(size=(120, 10)).astype(np.float32)
+    mb = (rng.uniform(size=(120, 10)) < 0.7).astype(np.int64)
+    uniq = rng.normal(size=(60, 10)).astype(np.float32)
+    mu = (rng.uniform(size=(60, 10)) < 0.7).astype(np.int64)
+    X = np.concatenate([base, base, base[:60], uniq], 0)       # rows 0-59 three times, 60-119 twice
+    data_m = np.concatenate([mb, mb, mb[:60], mu], 0)
+    widths = [1] * 10
+    off, _ = layout_of(widths)
+    W = orc.expand_cols(np.abs(rng.uniform(size=(10, 10))) * 0.05, off).astype(np.float32)
     out, tau, nval, lay = _attn_case(dev, X, W, data_m, widths, k, mode)
     _check_attn(out, tau, nval, lay, X, W, data_m, k)
 
