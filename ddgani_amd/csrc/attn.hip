@@ -471,7 +471,7 @@ __device__ __forceinline__ void set_wave_prio(int pr) {      // s_setprio takes 
 #ifndef FILT_PRIO
 #define FILT_PRIO(s) (3 - ((s) & 3))
 #endif
-#define FILT_CAPH 32                  // candidate slots per (query, lane half) and key chunk
+#define FILT_CAPH 64                  // candidate slots per (query, lane half) and key chunk
 
 // ---- screening pass over one chunk of the key lists: bf16 MFMA logits against the threshold each query
 // had when the chunk started; the key-list positions of everything that may reach the top-(k+1) are
