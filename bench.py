@@ -99,9 +99,14 @@ def pmc_traffic(workload, rows, kernel_prefix):
             d = json.load(open(f))
         except Exception:
             continue
+        tot = 0.0
+        hit = False
         for k, v in d.get("kernels", {}).items():
             if k.startswith(kernel_prefix) and "fetch_bytes_per_step" in v and "write_bytes_per_step" in v:
-                return v["fetch_bytes_per_step"] + v["write_bytes_per_step"], os.path.relpath(f, ROOT)
+                tot += v["fetch_bytes_per_step"] + v["write_bytes_per_step"]
+                hit = True
+        if hit:
+            return tot, os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -140,7 +145,7 @@ def main():
     out_code = torch.empty_like(Xq)
     merged = torch.empty_like(xd)
     sched_host = ops.schedule(T)
-    amode = ops.ATTN_BF16_FILTER if (a.attn_mode == "bf16filter" and k <= 31) else ops.ATTN_F32
+    amode = ops.ATTN_BF16_FILTER if (a.attn_mode == "bf16filter" and k <= ops.MAX_TOPK_REG) else ops.ATTN_F32
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     sel_ms, fill_ms, prep_ms, samp_ms = [], [], [], []
@@ -195,11 +200,11 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         sel = sum(sel_ms) / len(sel_ms)
-        n_launch = 1 if k <= 32 else 5                      # radix select = 5 launches of the same kernel
+        n_launch = 1 if k <= ops.MAX_TOPK_REG else 5                      # radix select = 5 launches of the same kernel
         flops = 2.0 * lay.D * pairs_local
         achieved = flops / (sel / n_launch * 1e-3) / 1e12
         filt = amode == ops.ATTN_BF16_FILTER
-        kname = "void k_attn_filt<" if filt else "void k_attn<"
+        kname = ("void k_attn_screen<", "void k_attn_rescore<", "void k_attn_warm<") if filt else "void k_attn<"
         peak = PEAK_BF16_MFMA_TFLOPS if filt else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = pmc_traffic(a.workload, N, kname) if world == 1 else (None, None)
         res = {
@@ -214,13 +219,15 @@ def main():
             "phases_ms": {"prepare(+allgather)": sum(prep_ms) / len(prep_ms), "select": sel,
                           "fill": sum(fill_ms) / len(fill_ms), "sampler+merge": sum(samp_ms) / len(samp_ms)},
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_attn_filt (bf16 MFMA similarity screening + exact top-k + fill)" if filt else
+                         "kernel": ("k_attn_screen (bf16 MFMA similarity screening; its time here includes the exact fp32 "
+                                    "k_attn_rescore and k_attn_warm launches of the select phase, about 12 % of it)" if filt else
                                     "k_attn<MODE_TOPK> (fp32 MFMA similarity + top-k + fill)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "launch_ms": sel / n_launch,
-                         "launches_note": ("one 'launch' = the key-chunk x workgroup-group launches of k_attn_filt of one "
-                                           "step (plus the 512-key fp32 warm-up kernel), timed together with HIP events on "
-                                           "the launch stream") if filt else "one launch per step"},
+                         "launches_note": ("one 'launch' = all key-chunk x workgroup-group launches of the select phase of one "
+                                           "step (k_attn_warm once per group, then k_attn_screen + k_attn_rescore per chunk), "
+                                           "timed together with HIP events on the launch stream; flops count only the "
+                                           "2*D*pairs*keys of the similarity") if filt else "one launch per step"},
         }
         if not a.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lay.widths, k, T, lay.D, N, a.cpu_rows)

@@ -16,6 +16,7 @@ from ._lib import DiscGrads, DiscWeights, GenGrads, GenWeights, TrainBatch, chec
 
 PRO_NONE, PRO_ADD_EMB, PRO_BN_RELU, PRO_EMB_RELU = 0, 1, 2, 3
 ATTN_F32, ATTN_BF16_FILTER = 0, 1
+MAX_TOPK_REG = 30      # DDG_MAX_TOPK_REG (include/ddgani.h): larger k takes the radix-select path
 _NAMES8 = ("betas", "alphas", "sqrt_alphas", "one_by_sqrt_alpha_s", "sqrt_beta_s", "alpha_cumulative",
            "sqrt_alpha_cumulative", "sqrt_one_minus_alpha_cumulative")
 
