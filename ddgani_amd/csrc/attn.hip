@@ -477,6 +477,17 @@ __device__ __forceinline__ void set_wave_prio(int pr) {      // s_setprio takes 
 // had when the chunk started; the key-list positions of everything that may reach the top-(k+1) are
 // appended to the lane's candidate slots.  No exact arithmetic, no lists: a pure MFMA stream.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// x * M for the small constants the row stride needs, without the quarter-rate 32-bit multiply
+template <int M>
+__device__ __forceinline__ uint32_t mul_small(uint32_t x) {
+    if constexpr (M % 3 == 0) {
+        uint32_t t;
+        asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(t) : "v"(x));
+        return t * (M / 3);
+    } else {
+        return x * M;
+    }
+}
 // keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
 __host__ __device__ constexpr int screen_stage_keys(int KS) { return KS <= 12 ? 128 : 64; }
 template <int KS>
@@ -659,17 +670,32 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     if (j == 0 && i < NPF) {             // rows of stage t+1 (in registers since stage t-1) -> LDS
                         const int idx = tid + FILT_NT * i;
                         const int row = idx / CPR, ch = idx - row * CPR;
+#ifdef EXP_NOCOMMIT
+                        asm volatile("" :: "v"(pf[i]), "v"(wr_n + row * RSTR + ch * 16));
+#else
                         *reinterpret_cast<u32x4 *>(wr_n + row * RSTR + ch * 16) = pf[i];
+#endif
                     }
                     if (j == 1 && i < NPF) {             // rows of stage t+2 (indices arrived a stage ago)
                         const int idx = tid + FILT_NT * i;
                         const int ch = idx - (idx / CPR) * CPR;
-                        pf[i] = *reinterpret_cast<const u32x4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
+                        // byte offset of the row = 32 * KS * index: a 32-bit shift-add and one 64-bit shift-add
+                        // instead of a quarter-rate 64-bit multiply (indices < 2^31 / KS: attn_check_dims)
+                        const uint64_t roff = (uint64_t)mul_small<KS>((uint32_t)kix[i]) << 5;
+#ifdef EXP_NOROWS
+                        asm volatile("" :: "v"(roff));
+#else
+                        pf[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.Xkh) + roff + ch * 16);
+#endif
                     }
                     if (j == 2 && i < NPF) {             // indices of stage t+3
                         const int row = (tid + FILT_NT * i) / CPR;
                         const int pos = stage_pos + 3 * TKS + row;
+#ifdef EXP_NOIDX
+                        asm volatile("" :: "v"(pos));
+#else
                         kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
+#endif
                     }
                     if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
                         const f32x16 &pa = cacc[(s + 1) & 1];
@@ -1339,6 +1365,7 @@ static int attn_check_dims(int64_t Nq, int64_t Nk, int C, int D, int mode) {
     if (Nq < 0 || Nk < 1 || C < 1 || D < 1) return DDG_E_ARG;
     if (mode != DDG_ATTN_F32 && mode != DDG_ATTN_BF16_FILTER) return DDG_E_ARG;
     if (ks4_for(D) == 0 || Nk >= (int64_t)1 << 31 || (Nq * C) / QPB + C >= (int64_t)1 << 31) return DDG_E_UNSUPPORTED;
+    if (mode == DDG_ATTN_BF16_FILTER && Nk >= (int64_t)1 << 27) return DDG_E_UNSUPPORTED;   // 32-bit row offsets / 16 in k_attn_screen
     return DDG_OK;
 }
 
