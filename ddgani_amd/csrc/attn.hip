@@ -493,8 +493,15 @@ __host__ __device__ constexpr int screen_stage_keys(int KS) { return KS <= 12 ? 
 template <int KS>
 __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
-    constexpr int RSTR = DP * 2 + 16;        // LDS row stride in bytes: conflict-free ds_read_b128
+    constexpr int RSTR = DP * 2;             // LDS row stride in bytes: rows are dense (the LDS-DMA image is lane-linear)
     constexpr int CPR = DP / 8;              // 16-byte chunks per key row
+    // Bank conflicts are avoided by an XOR swizzle of the chunk position inside the row, applied on the
+    // SOURCE address of the DMA and on the ds_read address.  A ds_read_b128 is served in groups of 16 lanes
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), bank = (byte / 4) mod 64.  Row strides of 32 / 96 dwords
+    // (KS 4, 12) alternate between two bank halves, so 8 positions x 2 row parities cover the 64 banks when
+    // rows of equal parity get distinct XOR keys: (row >> 1) & 7.  Strides of 64 / 128 dwords (KS 8, 16)
+    // need 16 distinct positions: key = row & 15.  Both keys are distinct inside every 16-lane group.
+    constexpr int SMASK = (KS % 8 == 4) ? 7 : 15;
     constexpr int TKS = screen_stage_keys(KS);   // keys per stage
     constexpr int NCH = TKS * CPR;
     constexpr int NPF = NCH / FILT_NT;
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     const int blk = p.blk_lo + (int)blockIdx.x;
     if (blk >= nblocks) return;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     if (tid == 0) s_col = block_column(p.qb_start, p.C, blk);
     __syncthreads();
@@ -555,31 +562,36 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     // is waited for.  Rows past the end of the chunk re-read its last key (no branch, no zero fill); the
     // candidate collection ignores them through `rem`.
     static_assert(NCH % FILT_NT == 0, "key stage must divide evenly over the workgroup");
+    // LDS unit n (16 bytes) of a stage buffer: wave `wid` fills pieces wid*NPF .. wid*NPF+NPF-1 of 1 KiB, lane l of
+    // piece q is unit 64 q + l = (row, position); it receives chunk position ^ key(row) of that key row.
     int kix[NPF];
-    u32x4 pf[NPF];
+    int urow[NPF];                            // row of the stage this lane fetches with piece i
+    uint32_t usrc[NPF];                       // byte offset of the source chunk inside the key row
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int n = (wid * NPF + i) * 64 + lane;
+        const int row = n / CPR, pos = n - row * CPR;
+        const int key = (SMASK == 7) ? ((row >> 1) & 7) : (row & 15);
+        urow[i] = row;
+        usrc[i] = (uint32_t)(((pos & ~SMASK) | ((pos ^ key) & SMASK)) * 16);
+    }
     auto load_idx = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int row = (tid + FILT_NT * i) / CPR;
-            const int pos = key_lo + t * TKS + row;
+            const int pos = key_lo + t * TKS + urow[i];
             kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
         }
     };
-    auto load_rows = [&]() {
-#pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + FILT_NT * i;
-            const int ch = idx - (idx / CPR) * CPR;
-            pf[i] = *reinterpret_cast<const u32x4 *>(p.Xkh + (int64_t)kix[i] * DP + ch * 8);
-        }
-    };
-    auto commit = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int idx = tid + FILT_NT * i;
-            const int row = idx / CPR, ch = idx - row * CPR;
-            *reinterpret_cast<u32x4 *>(kbuf(b) + row * RSTR + ch * 16) = pf[i];
-        }
+    // row bytes = 32 * KS * index: a 32-bit shift-add and one 64-bit add instead of a quarter-rate multiply
+    // (indices < 2^27: attn_check_dims)
+    uint32_t krow[NPF];                       // 3-bit-shifted row offset; written a half tile before the DMA: hipcc
+                                              // drains vmcnt(0) at a use of a plain load's result while a DMA is in flight
+    auto dma_piece = [&](int b, int i) {
+        const uint64_t roff = ((uint64_t)krow[i] << 5) + usrc[i];
+        __builtin_amdgcn_global_load_lds(
+            reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(p.Xkh) + roff),
+            reinterpret_cast<__attribute__((address_space(3))) void *>(
+                (uint32_t)(uintptr_t)(kbuf(b) + (wid * NPF + i) * 1024)), 16, 0, 0);
     };
 
     // the not-so-rare path of one 32-key tile (about one tile in five at 1M rows): which of the lane's 16
@@ -609,32 +621,50 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     // The key stream is one unbroken software pipeline of half tiles (H MFMAs each), written out by hand.
     // Every MFMA slot carries the ds_read of the fragment that the slot H positions later consumes -- at
     // the end of a stage that is already the first fragment of the next stage's buffer -- plus one filler:
-    // an LDS write of the next stage's rows, a global load of the stage after (rows, then key-list
-    // indices), or a max3 of the previous tile's logits.  sched_barrier keeps the slots as written.  Two
-    // accumulator sets alternate, so a tile's threshold test runs one tile late, beside the next tile's
-    // MFMAs.  One workgroup barrier per stage, between the writes of buffer t+1 and its first read; no
-    // wait precedes it: LDS operations of a wave complete in order and the fragment reads consumed since
-    // the writes are younger than them.  Three buffers make the write of stage t+1 safe without a second
-    // barrier: its buffer was last read in stage t-2, which every wave left before the barrier of t-1.
+    // a key-list index load of stage t+2 (first half tile), a max3 of the previous tile's logits (second
+    // halves), or an LDS-DMA piece of stage t+2's key rows (last half tile).  sched_barrier keeps the
+    // slots as written.  Two accumulator sets alternate, so a tile's threshold test runs one tile late,
+    // beside the next tile's MFMAs.
+    // Synchronisation, three stage buffers: the DMA of stage t+1 was issued in the last half tile of stage
+    // t-1; each wave retires its own pieces with a counted vmcnt (the younger index loads stay in flight)
+    // before the one barrier of stage t, which precedes the last half tile -- the first reader of buffer
+    // t+1.  The DMA of stage t+2 is issued after that barrier into the buffer of stage t-1, whose last
+    // fragment reads were issued before the barrier of stage t-1 and consumed a whole stage ago.
     constexpr int H = KS / 2;
     constexpr int NT_STAGE = TKS / 32;
     static_assert(NPF <= H && NT_STAGE >= 2 && NT_STAGE % 2 == 0, "slot plan");
     const int nst = (key_hi - key_lo + TKS - 1) / TKS;
     load_idx(0);
-    load_rows();
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) krow[i] = mul_small<KS>((uint32_t)kix[i]);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) dma_piece(0, i);
     load_idx(1);
-    commit(0);
-    load_rows();
-    load_idx(2);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) krow[i] = mul_small<KS>((uint32_t)kix[i]);
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) dma_piece(1, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int lds_lane = r32 * RSTR + h * 16;
+    // fragment st of tile row r32: chunk 2 st + h, stored at position chunk ^ key(r32); the low bits of the
+    // chunk take SMASK/2+1 values, one precomputed lane offset each
+    constexpr int NOFF = (SMASK + 1) / 2;
+    int foff[NOFF];
+    {
+        const int key = (SMASK == 7) ? ((r32 >> 1) & 7) : (r32 & 15);
+#pragma unroll
+        for (int m = 0; m < NOFF; ++m) foff[m] = r32 * RSTR + (((2 * m + h) ^ key) & SMASK) * 16;
+    }
+    auto frag = [&](const char *buf, int tile, int st) {
+        return *reinterpret_cast<const bf16x8 *>(buf + foff[st % NOFF] + tile * 32 * RSTR + ((2 * st) & ~SMASK) * 16);
+    };
     bf16x8 fr[2][H];
     f32x16 cacc[2];
     float mx[2] = {0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 16; ++g) { cacc[0][g] = 0.f; cacc[1][g] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < H; ++i) fr[0][i] = *reinterpret_cast<const bf16x8 *>(kbuf(0) + lds_lane + i * 32);
+    for (int i = 0; i < H; ++i) fr[0][i] = frag(kbuf(0), 0, i);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef FILT_TIMING
     unsigned long long tm_bar = 0, tm_coll = 0, ts_begin = TSTAMP();
@@ -642,9 +672,9 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     int b_cur = 0, b_nxt = 1;
 #pragma unroll 1
     for (int t = 0; t < nst; ++t) {
-        const char *base = kbuf(b_cur) + lds_lane;
-        const char *base_n = kbuf(b_nxt) + lds_lane;
-        char *wr_n = kbuf(b_nxt);
+        const char *base = kbuf(b_cur);
+        const char *base_n = kbuf(b_nxt);
+        const int b_nn = 3 - b_cur - b_nxt;
         const int stage_pos = key_lo + t * TKS;
         const int rem_stage = key_hi - stage_pos;
 #pragma unroll
@@ -664,39 +694,15 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     }
                     cacc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[u * H + i], cacc[s & 1], 0, 0, 0);
                     if (j + 1 < 2 * NT_STAGE)
-                        fr[(j + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(base + ((j + 1) >> 1) * 32 * RSTR + (((j + 1) & 1) * H + i) * 32);
+                        fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
                     else
-                        fr[0][i] = *reinterpret_cast<const bf16x8 *>(base_n + i * 32);
-                    if (j == 0 && i < NPF) {             // rows of stage t+1 (in registers since stage t-1) -> LDS
-                        const int idx = tid + FILT_NT * i;
-                        const int row = idx / CPR, ch = idx - row * CPR;
-#ifdef EXP_NOCOMMIT
-                        asm volatile("" :: "v"(pf[i]), "v"(wr_n + row * RSTR + ch * 16));
-#else
-                        *reinterpret_cast<u32x4 *>(wr_n + row * RSTR + ch * 16) = pf[i];
-#endif
-                    }
-                    if (j == 1 && i < NPF) {             // rows of stage t+2 (indices arrived a stage ago)
-                        const int idx = tid + FILT_NT * i;
-                        const int ch = idx - (idx / CPR) * CPR;
-                        // byte offset of the row = 32 * KS * index: a 32-bit shift-add and one 64-bit shift-add
-                        // instead of a quarter-rate 64-bit multiply (indices < 2^31 / KS: attn_check_dims)
-                        const uint64_t roff = (uint64_t)mul_small<KS>((uint32_t)kix[i]) << 5;
-#ifdef EXP_NOROWS
-                        asm volatile("" :: "v"(roff));
-#else
-                        pf[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.Xkh) + roff + ch * 16);
-#endif
-                    }
-                    if (j == 2 && i < NPF) {             // indices of stage t+3
-                        const int row = (tid + FILT_NT * i) / CPR;
-                        const int pos = stage_pos + 3 * TKS + row;
-#ifdef EXP_NOIDX
-                        asm volatile("" :: "v"(pos));
-#else
+                        fr[0][i] = frag(base_n, 0, i);
+                    if (j == 0 && i < NPF) {             // key-list indices of stage t+2
+                        const int pos = stage_pos + 2 * TKS + urow[i];
                         kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
-#endif
                     }
+                    if (j == 2 * NT_STAGE - 2 && i < NPF) krow[i] = mul_small<KS>((uint32_t)kix[i]);
+                    if (j == 2 * NT_STAGE - 1 && i < NPF) dma_piece(b_nn, i);   // key rows of stage t+2
                     if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
                         const f32x16 &pa = cacc[(s + 1) & 1];
 #pragma unroll
@@ -706,13 +712,18 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (j == 2 * NT_STAGE - 2) {             // buffer t+1 complete in every wave before its first read
+                if (j == 2 * NT_STAGE - 2) {
+                    // own DMA pieces of stage t+1 landed (the NPF index loads issued since may still fly),
+                    // then every wave's: buffer t+1 is complete before its first read
 #ifdef FILT_TIMING
                     const unsigned long long tb0 = TSTAMP();
-                    asm volatile("s_barrier" ::: "memory");
+#endif
+                    if constexpr (NPF == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+                    else if constexpr (NPF == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                    else if constexpr (NPF == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef FILT_TIMING
                     tm_bar += TSTAMP() - tb0;
-#else
-                    asm volatile("s_barrier" ::: "memory");
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -727,10 +738,10 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const int b_old = b_cur;
         b_cur = b_nxt;
-        b_nxt = 3 - b_old - b_nxt;
+        b_nxt = b_nn;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the stages past the end must not outlive the wave
     set_wave_prio(0);
     {                                                    // last tile of the chunk
         const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
@@ -1291,7 +1302,7 @@ static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_byte
 
 template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
-    const size_t lds = (size_t)3 * screen_stage_keys(KS) * (KS * 32 + 16);
+    const size_t lds = (size_t)3 * screen_stage_keys(KS) * (KS * 32);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
     static size_t granted = 48 * 1024, granted_w = 48 * 1024;
     int rc = set_lds_attr((const void *)k_attn_screen<KS>, lds, granted);
