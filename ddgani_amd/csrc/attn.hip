@@ -564,23 +564,30 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     static_assert(NCH % FILT_NT == 0, "key stage must divide evenly over the workgroup");
     // LDS unit n (16 bytes) of a stage buffer: wave `wid` fills pieces wid*NPF .. wid*NPF+NPF-1 of 1 KiB, lane l of
     // piece q is unit 64 q + l = (row, position); it receives chunk position ^ key(row) of that key row.
-    int kix[NPF];
-    int urow[NPF];                            // row of the stage this lane fetches with piece i
+    // The pieces of wave `wid` cover exactly the rows [wid*RPW, wid*RPW + RPW) of the stage: one index load per
+    // wave and stage (lane l fetches the index of row l % RPW), handed to the lanes of a piece by ds_bpermute.
+    constexpr int RPW = TKS / FILT_NW;        // key rows per wave and stage
+    static_assert(RPW * CPR == NPF * 64 && RPW <= 64, "a wave's pieces cover whole rows");
+    int kix = 0;
+    int urow4[NPF];                           // 4 * (row of the stage this lane fetches with piece i, relative to the wave)
     uint32_t usrc[NPF];                       // byte offset of the source chunk inside the key row
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-        const int n = (wid * NPF + i) * 64 + lane;
-        const int row = n / CPR, pos = n - row * CPR;
+        const int n = i * 64 + lane;
+        const int rrow = n / CPR, pos = n - rrow * CPR;
+        const int row = wid * RPW + rrow;
         const int key = (SMASK == 7) ? ((row >> 1) & 7) : (row & 15);
-        urow[i] = row;
+        urow4[i] = rrow * 4;
         usrc[i] = (uint32_t)(((pos & ~SMASK) | ((pos ^ key) & SMASK)) * 16);
     }
     auto load_idx = [&](int t) {
+        const int pos = key_lo + t * TKS + wid * RPW + (lane % RPW);
+        kix = kl[pos < key_hi ? pos : key_hi - 1];
+    };
+    auto row_offsets = [&](uint32_t (&kr)[NPF]) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int pos = key_lo + t * TKS + urow[i];
-            kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
-        }
+        for (int i = 0; i < NPF; ++i)
+            kr[i] = mul_small<KS>((uint32_t)__builtin_amdgcn_ds_bpermute(urow4[i], kix));
     };
     // row bytes = 32 * KS * index: a 32-bit shift-add and one 64-bit add instead of a quarter-rate multiply
     // (indices < 2^27: attn_check_dims)
@@ -595,27 +602,25 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     };
 
     // the not-so-rare path of one 32-key tile (about one tile in five at 1M rows): which of the lane's 16
-    // logits reach the threshold.  Branch-free bit mask (the per-g branches of a naive version cost several
-    // hundred cycles a call, and a stage waits for its slowest wave); only lanes with a hit enter the loop.
-    auto collect = [&](const f32x16 &acc, int tile_pos, int rem) {
+    // logits reach the threshold.  It is on the wave's critical path and a stage waits for its slowest
+    // wave, so it is kept short and branch-free: a 16-bit mask of the hits, stored with the tile's number
+    // as ONE word per lane and tile.  k_attn_rescore unpacks the words (and drops the padding rows past the
+    // end of the chunk, which hold copies of its last key).
+    auto collect = [&](const f32x16 &acc, int tile) {
 #ifdef FILT_NOCOLLECT      // timing experiments only (wrong results): what this path costs
         ++ncand; return;
 #endif
         unsigned cm = 0;
 #pragma unroll
         for (int g = 0; g < 16; ++g) cm |= (acc[g] > thr_adj) ? (1u << g) : 0u;
-        if (rem < 32) {                                  // last tile of the chunk: drop the padding rows
-            unsigned vm = 0;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) vm |= ((g & 3) + 8 * (g >> 2) + 4 * h < rem) ? (1u << g) : 0u;
-            cm &= vm;
-        }
-        while (cm) {
-            const int g = __ffs((int)cm) - 1;
-            cm &= cm - 1;
-            if (ncand < FILT_CAPH) cand[(int64_t)ncand * FILT_NT] = tile_pos + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (cm) {
+            if (ncand < FILT_CAPH) cand[ncand * FILT_NT] = (int32_t)(((unsigned)tile << 16) | cm);
             ++ncand;
         }
+    };
+    // the 8 operations of a tile's row maximum, one at a time (slot fillers)
+    auto max_op = [&](const f32x16 &pa, float &m, int o) {
+        m = (o == 0) ? fmaxf(pa[0], pa[1]) : fmaxf(fmaxf(m, pa[2 * o]), pa[2 * o + 1]);
     };
 
     // The key stream is one unbroken software pipeline of half tiles (H MFMAs each), written out by hand.
@@ -635,13 +640,11 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     static_assert(NPF <= H && NT_STAGE >= 2 && NT_STAGE % 2 == 0, "slot plan");
     const int nst = (key_hi - key_lo + TKS - 1) / TKS;
     load_idx(0);
-#pragma unroll
-    for (int i = 0; i < NPF; ++i) krow[i] = mul_small<KS>((uint32_t)kix[i]);
+    row_offsets(krow);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) dma_piece(0, i);
     load_idx(1);
-#pragma unroll
-    for (int i = 0; i < NPF; ++i) krow[i] = mul_small<KS>((uint32_t)kix[i]);
+    row_offsets(krow);
 #pragma unroll
     for (int i = 0; i < NPF; ++i) dma_piece(1, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     for (int i = 0; i < H; ++i) fr[0][i] = frag(kbuf(0), 0, i);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef FILT_TIMING
-    unsigned long long tm_bar = 0, tm_coll = 0, ts_begin = TSTAMP();
+    unsigned long long tm_bar = 0, tm_coll = 0, tm_vm = 0, tm_ct = 0, ts_begin = TSTAMP();
 #endif
     int b_cur = 0, b_nxt = 1;
 #pragma unroll 1
@@ -675,8 +678,6 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         const char *base = kbuf(b_cur);
         const char *base_n = kbuf(b_nxt);
         const int b_nn = 3 - b_cur - b_nxt;
-        const int stage_pos = key_lo + t * TKS;
-        const int rem_stage = key_hi - stage_pos;
 #pragma unroll
         for (int s = 0; s < NT_STAGE; ++s) {
             // The SIMD's arbiter favours its oldest wave, and a dependent MFMA chain is always ready: left
@@ -697,31 +698,31 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                         fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
                     else
                         fr[0][i] = frag(base_n, 0, i);
-                    if (j == 0 && i < NPF) {             // key-list indices of stage t+2
-                        const int pos = stage_pos + 2 * TKS + urow[i];
-                        kix[i] = kl[pos < key_hi ? pos : key_hi - 1];
-                    }
-                    if (j == 2 * NT_STAGE - 2 && i < NPF) krow[i] = mul_small<KS>((uint32_t)kix[i]);
+                    if (j == 0 && i == 0) load_idx(t + 2);        // key-list indices of stage t+2
+                    if (j == 2 * NT_STAGE - 2 && i < NPF)
+                        krow[i] = mul_small<KS>((uint32_t)__builtin_amdgcn_ds_bpermute(urow4[i], kix));
                     if (j == 2 * NT_STAGE - 1 && i < NPF) dma_piece(b_nn, i);   // key rows of stage t+2
                     if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
-                        const f32x16 &pa = cacc[(s + 1) & 1];
 #pragma unroll
                         for (int o = 0; o < 8; ++o)
-                            if (o * H / 8 == i)
-                                mx[(s + 1) & 1] = (o == 0) ? fmaxf(pa[0], pa[1]) : fmaxf(fmaxf(mx[(s + 1) & 1], pa[2 * o]), pa[2 * o + 1]);
+                            if (o * H / 8 == i) max_op(cacc[(s + 1) & 1], mx[(s + 1) & 1], o);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (j == 2 * NT_STAGE - 2) {
-                    // own DMA pieces of stage t+1 landed (the NPF index loads issued since may still fly),
+                    // own DMA pieces of stage t+1 landed (the index load issued since may still fly),
                     // then every wave's: buffer t+1 is complete before its first read
 #ifdef FILT_TIMING
                     const unsigned long long tb0 = TSTAMP();
 #endif
-                    if constexpr (NPF == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-                    else if constexpr (NPF == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-                    else if constexpr (NPF == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef FILT_TIMING
+                    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    const unsigned long long tb1 = TSTAMP();
+                    tm_vm += tb1 - tb0;
+                    asm volatile("s_barrier" ::: "memory");
+#else
+                    asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+#endif
 #ifdef FILT_TIMING
                     tm_bar += TSTAMP() - tb0;
 #endif
@@ -732,8 +733,12 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 if (__builtin_amdgcn_ballot_w64(mx[(s + 1) & 1] > thr_adj) != 0) {
 #ifdef FILT_TIMING
                     ++tm_coll;
+                    const unsigned long long tc0 = TSTAMP();
+                    collect(cacc[(s + 1) & 1], t * NT_STAGE + s - 1);
+                    tm_ct += TSTAMP() - tc0;
+#else
+                    collect(cacc[(s + 1) & 1], t * NT_STAGE + s - 1);
 #endif
-                    collect(cacc[(s + 1) & 1], stage_pos + (s - 1) * 32, rem_stage - (s - 1) * 32);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -745,16 +750,15 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     set_wave_prio(0);
     {                                                    // last tile of the chunk
         const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
-        float m = fmaxf(pa[0], pa[1]);
+        float m = 0.f;
 #pragma unroll
-        for (int g = 2; g < 16; g += 2) m = fmaxf(fmaxf(m, pa[g]), pa[g + 1]);
-        if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0)
-            collect(pa, key_lo + nst * TKS - 32, key_hi - (key_lo + nst * TKS - 32));
+        for (int o = 0; o < 8; ++o) max_op(pa, m, o);
+        if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0) collect(pa, nst * NT_STAGE - 1);
     }
 #ifdef FILT_TIMING
     if (lane == 0) {
         atomicAdd(&g_filt_time[2], tm_bar); atomicAdd(&g_filt_time[3], (unsigned long long)nst);
-        atomicAdd(&g_filt_time[4], TSTAMP() - ts_begin); atomicAdd(&g_filt_time[5], tm_coll);
+        atomicAdd(&g_filt_time[4], TSTAMP() - ts_begin); atomicAdd(&g_filt_time[5], tm_coll); atomicAdd(&g_filt_time[6], tm_vm); atomicAdd(&g_filt_time[7], tm_ct);
     }
 #endif
     p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
@@ -811,9 +815,25 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_rescore(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < KS / 4; ++i) wreg[i] = *reinterpret_cast<const f32x4 *>(wq + 4 * i);
 
-    for (int r = 0; __any(r < ncand); ++r) {
-        const bool has = r < ncand;
-        const int mypos = has ? cand[(int64_t)r * FILT_NT] : 0;
+    // candidate words of k_attn_screen: (tile of the chunk << 16) | mask of the lane's 16 logits of that tile
+    const int key_end = p.key_hi < nk ? p.key_hi : nk;
+    int ent = 0, tpos = 0;
+    unsigned msk = 0;
+    while (__any(msk != 0 || ent < ncand)) {
+        if (msk == 0 && ent < ncand) {
+            const unsigned w = (unsigned)cand[(int64_t)ent * FILT_NT];
+            ++ent;
+            msk = w & 0xffffu;
+            tpos = p.key_lo + (int)(w >> 16) * 32 + 4 * h;
+        }
+        bool has = msk != 0;
+        int mypos = 0;
+        if (has) {
+            const int g = __ffs((int)msk) - 1;
+            msk &= msk - 1;
+            mypos = tpos + (g & 3) + 8 * (g >> 2);
+            has = mypos < key_end;                       // padding rows of the chunk's last stage
+        }
         const int mykidx = has ? kl[mypos] : 0;
         float mysv = -INFINITY;
         unsigned long long bal = __ballot(has);
@@ -1214,7 +1234,7 @@ struct AttnWs {
 // chunk is screened against the thresholds the queries had when it started, so a chunk as long as the
 // prefix before it yields about k+1 candidates per query; the cap keeps a chunk's bf16 rows inside the
 // Infinity Cache.  DDG_FILT_CHUNK (multiple of 128) forces a fixed chunk length: tests use a small one.
-#define FILT_CHUNK_MAX 262144
+#define FILT_CHUNK_MAX 262144       // <= 65536 tiles of 32 keys: the tile number of a candidate word has 16 bits
 static int64_t filt_chunk_fixed() {
     static int64_t v = -1;
     if (v < 0) {
