@@ -423,11 +423,14 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
 // on the bf16 MFMA (v_mfma_f32_32x32x16_bf16: 16x the fp32-matrix rate, half the key bytes).  For
 // q = W[c]*x_j and key k:  | sum_d bf16(q_d) bf16(k_d) (fp32 accumulate) - sum_d q_d k_d |
 //      <= (2^-7 (1 + 2^-9) + DP 2^-23) * sum_d |q_d||k_d|  <=  FILT_EPS * ||q||_2 * ||k||_2 .
-// A key can only belong to the k+1 largest exact logits if its screened logit exceeds the current
-// exact (k+1)-th largest minus that margin (with max_i ||k_i|| for ||k||).  Every such candidate is
-// re-scored EXACTLY in fp32 (the wave computes sum_d (w_d x_d) k_d cooperatively from the fp32
-// tables) and only exact values enter the top-(k+1) list, so the kept set is the fp32 one.
-// Workgroup = 8 waves x 32 queries of one column sharing one key stream (stages of 128 keys).
+// A key can only belong to the k+2 largest exact logits (NLIST) if its screened logit exceeds the current
+// exact (k+2)-th largest minus that margin (with max_i ||k_i|| for ||k||).  Every such candidate is
+// re-scored EXACTLY in fp32 (16 lanes compute sum_d (w_d x_d) k_d cooperatively from the fp32 tables) and
+// only exact values enter the top-(k+2) list, so the kept set is the fp32 one.
+// Three kernels per group of workgroups (launch_filt): k_attn_warm (first WARMK key positions, fp32 MFMA,
+// gives every pair a threshold), then per key chunk k_attn_screen (bf16 MFMA stream, thresholds frozen
+// at the chunk start, survivors recorded) and k_attn_rescore (exact pass over the survivors, list update,
+// fill at the last chunk).  Workgroup = 8 waves x 32 queries of one column sharing one key stream.
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifdef FILT_STATS   // experiments only: [0] re-scored, [2] batches, [3] tie-flagged pairs
