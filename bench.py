@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--attn-mode", default="bf16filter", choices=["f32", "bf16filter"],
                     help="similarity arithmetic of the attention fill (include/ddgani.h: DDG_ATTN_*)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
+                                                     "multi-rank path on a one-GPU box together with --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--cpu-rows", type=int, default=2048, help="sample rows for the CPU attention-fill timing")
     return ap.parse_args()
 
@@ -115,10 +118,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from ddgani_amd import ops, synth
     from ddgani_amd import dist as ddist
@@ -193,7 +201,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

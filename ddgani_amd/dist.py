@@ -22,11 +22,21 @@ class Comm:
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
+        # gloo (CPU tests, one-GPU rehearsals of the multi-rank path) moves device tensors through the host;
+        # nccl (= RCCL, the production backend) works on device memory directly
+        self.host_staged = self.on and dist.get_backend(group) == "gloo"
 
     def all_gather_rows(self, t: torch.Tensor, counts) -> torch.Tensor:
         """concatenate the ranks' row shards (shard sizes ``counts``) along dim 0"""
         if not self.on:
             return t
+        if self.host_staged and t.is_cuda:
+            dev = t.device
+            self.host_staged = False
+            try:
+                return self.all_gather_rows(t.cpu(), counts).to(dev)
+            finally:
+                self.host_staged = True
         if len(set(counts)) == 1:
             out = torch.empty((sum(counts),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
@@ -41,7 +51,12 @@ class Comm:
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.on:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.host_staged and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
 
