@@ -492,7 +492,7 @@ __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
     }
 }
 // keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
-__host__ __device__ constexpr int screen_stage_keys(int KS) { return KS <= 12 ? 128 : 64; }
+__host__ __device__ constexpr int screen_stage_keys(int KS) { return (FILT_NW == 8 && KS <= 12) ? 128 : 64; }
 template <int KS>
 __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
@@ -1232,20 +1232,16 @@ struct AttnWs {
     int nchunk_k, nchunk_q;
 };
 
-#define FILT_GROUP 16384       // workgroups per launch group of the filter kernel (bounds the parked state)
+#define FILT_GROUP (16384 * 8 / FILT_NW)       // workgroups per launch group of the filter kernel (bounds the parked state)
 // Key chunks of the screening path: [WARMK, 2 WARMK), then doubling up to FILT_CHUNK_MAX positions.  A
 // chunk is screened against the thresholds the queries had when it started, so a chunk as long as the
 // prefix before it yields about k+1 candidates per query; the cap keeps a chunk's bf16 rows inside the
 // Infinity Cache.  DDG_FILT_CHUNK (multiple of 128) forces a fixed chunk length: tests use a small one.
 #define FILT_CHUNK_MAX 262144       // <= 65536 tiles of 32 keys: the tile number of a candidate word has 16 bits
-static int64_t filt_chunk_fixed() {
-    static int64_t v = -1;
-    if (v < 0) {
-        const char *e = getenv("DDG_FILT_CHUNK");
-        int64_t c = e ? atoll(e) : 0;
-        v = c <= 0 ? 0 : (c < 128 ? 128 : (c / 128) * 128);
-    }
-    return v;
+static int64_t filt_chunk_fixed() {       // read per call: tests switch schedules inside one process
+    const char *e = getenv("DDG_FILT_CHUNK");
+    const int64_t c = e ? atoll(e) : 0;
+    return c <= 0 ? 0 : (c < 128 ? 128 : (c / 128) * 128);
 }
 
 static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int D, int64_t k, bool same) {
@@ -1556,6 +1552,10 @@ extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk
         attn_args(a, w, w.L2, Nk, C, D, kk);
         a.out_code = out_code;
         if ((rc = dispatch_select(a, nb128, DDG_ATTN_F32, D, s))) return rc;
+        if (out_tau) {      // pairs that overflowed their candidate slots parked an incomplete list: tau from the fp32 pass
+            k_write_debug<<<(unsigned)nb128, QPB, 0, s>>>(w.L2.qlist, w.L2.tau, w.L2.qb_start, w.nk, C, out_tau, nullptr);
+            DDG_CHECK_LAUNCH();
+        }
         if ((rc = compact_pairs(w, w.L2, QPB, w.L3, C, s))) return rc;
         open = &w.L3;
     }
