@@ -471,6 +471,12 @@ __device__ __forceinline__ void set_wave_prio(int pr) {      // s_setprio takes 
         default: __builtin_amdgcn_s_setprio(3); break;
     }
 }
+#ifndef FILT_RENDEZVOUS
+#define FILT_SPLIT_BARRIER              // -DFILT_RENDEZVOUS: one plain s_barrier per stage instead (A/B builds)
+#endif
+#ifndef FILT_SIG_J
+#define FILT_SIG_J 1                 // half tile after which a wave arrives at the split barrier (0..3 measured: 1 is best)
+#endif
 #ifndef FILT_PRIO
 #define FILT_PRIO(s) (3 - ((s) & 3))
 #endif
@@ -511,6 +517,9 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     auto kbuf = [&](int b) -> char * { return fsm + b * (TKS * RSTR); };      // three stage buffers
     __shared__ int s_col;
+#ifdef FILT_SPLIT_BARRIER
+    __shared__ unsigned s_sync;               // waves that have their DMA pieces of stages 1 .. t+1 in LDS, summed
+#endif
 
     const int nblocks = p.qb_start[p.C];
     const int blk = p.blk_lo + (int)blockIdx.x;
@@ -519,6 +528,9 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, h = lane >> 5;
     if (tid == 0) s_col = block_column(p.qb_start, p.C, blk);
+#ifdef FILT_SPLIT_BARRIER
+    if (tid == 0) s_sync = 0;
+#endif
     __syncthreads();
     const int c = s_col;
     const int nk = p.nk[c];
@@ -712,25 +724,43 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#ifdef FILT_SPLIT_BARRIER
+                // Split barrier.  Arrive (mid-stage): this wave's DMA pieces of stage t+1 have landed -> one LDS
+                // atomic by one lane (exec set by hand: no control flow in the tile stream).  Wait (before the
+                // last half tile, the first reader of buffer t+1): all FILT_NW waves have arrived for stage t.
+                // A wave can run about half a stage ahead of the slowest one instead of stopping at a
+                // rendezvous.  The DMA of stage t+2, issued after the wait, overwrites the buffer of stage t-1:
+                // every wave has arrived for stage t, so it is past the middle of stage t and has consumed its
+                // fragments of stage t-1.
+                if (j == FILT_SIG_J) {
+                    unsigned long long sv;
+                    asm volatile("s_waitcnt vmcnt(1)\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(sv) : "v"((uint32_t)(uintptr_t)&s_sync), "v"(1u) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (j == 2 * NT_STAGE - 2) {
+                    const unsigned target = (unsigned)FILT_NW * (unsigned)(t + 1);
+                    while (__builtin_amdgcn_readfirstlane(*(volatile unsigned *)&s_sync) < target) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
                 if (j == 2 * NT_STAGE - 2) {
                     // own DMA pieces of stage t+1 landed (the index load issued since may still fly),
                     // then every wave's: buffer t+1 is complete before its first read
 #ifdef FILT_TIMING
                     const unsigned long long tb0 = TSTAMP();
-#endif
-#ifdef FILT_TIMING
                     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     const unsigned long long tb1 = TSTAMP();
                     tm_vm += tb1 - tb0;
                     asm volatile("s_barrier" ::: "memory");
+                    tm_bar += TSTAMP() - tb0;
 #else
                     asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
 #endif
-#ifdef FILT_TIMING
-                    tm_bar += TSTAMP() - tb0;
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
             }
             if (s > 0 || t > 0) {                        // the tile before this one (s == 0: the previous stage's last)
                 if (__builtin_amdgcn_ballot_w64(mx[(s + 1) & 1] > thr_adj) != 0) {
