@@ -92,6 +92,9 @@ SIGNATURES = {
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddg_attn_fill": (C.c_int, [C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int,
                                 C.c_int, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_learner_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ddg_learner_train": (C.c_int, [c_f32p, c_i32p, C.c_int64, c_f32p, c_i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, c_f32p, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

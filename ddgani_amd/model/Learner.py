@@ -1,9 +1,10 @@
 """Mirror of the reference's ``model/Learner.py`` ("data-utility plug-in"): a one-layer softmax
 classifier trained for ``epoch`` full-batch SGD steps on the imputed code, whose validation loss
 enters the generator loss only as a constant (computed under no_grad, model/Learner.py:62-64).
-SURVEY.md 8(f) row 1 ("next"): kept in stock torch ops on the tensors' device for now; it is
-numerically inert for the imputation except that it RE-SEEDS torch's global RNG (:44), which is
-reproduced here because it changes the noise stream of the following epochs."""
+SURVEY.md 8(f) row 1: the SGD steps and the validation pass run in ``ddg_learner_train`` (csrc/learner.hip),
+one fused pass over the training rows per step; the module below only reproduces the reference's parameter
+construction, because it RE-SEEDS torch's global RNG (:44) and its initialisers consume that stream, which
+changes the noise of the following epochs."""
 from __future__ import annotations
 
 import torch
@@ -30,21 +31,12 @@ class L(nn.Module):
 
 
 def train_L_code(epoch, x_train, y_train, x_valid, y_valid, label_num, device):
-    """reference: model/Learner.py:43-67 -> (validation loss tensor, validation accuracy)."""
+    """reference: model/Learner.py:43-67 -> (validation loss tensor, validation accuracy).
+    Only fc2 is used by the reference's forward (:36-40), so only its parameters are trained."""
+    from .. import ops
     torch.manual_seed(3407)
     net = L(x_train.size()[1], label_num).to(device)
-    opt = optim.SGD(net.parameters(), lr=0.01)
-    criterion = nn.CrossEntropyLoss()
-    xt = x_train.detach()
-    yt = y_train.squeeze().long()
-    for _ in range(epoch):
-        loss = criterion(net(xt), yt)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-    with torch.no_grad():
-        Y = net(x_valid)
-        yv = y_valid.squeeze().long()
-        val_loss = criterion(Y, yv)
-        accuracy = (torch.max(Y.data, dim=1)[1] == yv).sum().item() / y_valid.size(0)
+    W = net.fc2.weight.data.contiguous()
+    b = net.fc2.bias.data.contiguous()
+    val_loss, accuracy = ops.learner_train(x_train, y_train, x_valid, y_valid, W, b, epoch, lr=0.01)
     return val_loss, accuracy

@@ -399,3 +399,26 @@ class AttnPlan:
                                   self.mode, self.alias, _ptr(self.out), _ptr(tau), _ptr(nval), self.ws.data_ptr(),
                                   self.ws.numel(), _stream()), "ddg_attn_fill")
         return (self.out, tau, nval) if debug else self.out
+
+
+# ----------------------------------------------------------------------------- 8(f) row 1: Learner
+def learner_train(x_train, y_train, x_valid, y_valid, W, b, epochs: int, lr: float = 0.01):
+    """``epochs`` full-batch SGD steps of the reference's Learner (model/Learner.py:43-67) on the device, then its
+    validation loss and accuracy.  W [L, D] / b [L]: fc2 parameters, updated in place.
+    -> (val_loss: 0-dim device tensor, accuracy: float)"""
+    L, D = W.shape
+    dev = W.device
+    xt = x_train.detach().to(torch.float32).contiguous()
+    xv = x_valid.detach().to(torch.float32).contiguous()
+    yt = y_train.reshape(-1).to(torch.int32).contiguous()
+    yv = y_valid.reshape(-1).to(torch.int32).contiguous()
+    if xt.shape[1] != D or xv.shape[1] != D or yt.numel() != xt.shape[0] or yv.numel() != xv.shape[0]:
+        raise _lib.DdgError("learner_train: shape mismatch")
+    ws = torch.empty(lib().ddg_learner_workspace_bytes(D, L), dtype=torch.uint8, device=dev)
+    out_loss = torch.empty(1, dtype=torch.float32, device=dev)
+    out_hit = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib().ddg_learner_train(_ptr(xt, torch.float32), _ptr(yt, torch.int32), xt.shape[0], _ptr(xv, torch.float32),
+                                  _ptr(yv, torch.int32), xv.shape[0], D, L, int(epochs), float(lr),
+                                  _ptr(W, torch.float32), _ptr(b, torch.float32), _ptr(out_loss), _ptr(out_hit),
+                                  ws.data_ptr(), ws.numel(), _stream()), "ddg_learner_train")
+    return out_loss[0], int(out_hit.item()) / xv.shape[0]

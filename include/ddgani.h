@@ -286,6 +286,24 @@ int ddg_attn_fill(const int32_t *offsets_host, int64_t n_query_rows, int64_t n_k
                   int64_t k, int mode, int queries_alias_keys, float *out_code, float *out_tau,
                   int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * (f1) the "data-utility" Learner: train_L_code                 model/Learner.py:43-67
+ *
+ * `epochs` full-batch SGD steps (learning rate `lr`, the reference uses 0.01) of
+ *   p = softmax(x W^T + b),  loss = CrossEntropyLoss(p, y)   (log_softmax applied to p again, :36-39, :47)
+ * on the training rows, then the same loss and the number of correct arg-max predictions on the
+ * validation rows (:61-66).  W [L][D] and b [L] are the fc2 parameters of the reference's `L` module:
+ * initial values in (the caller draws them with the reference's seed and construction order, :44-45),
+ * trained values out.  x_*: [n][D] fp32, y_*: int32 class indices in [0, L).  One fused pass over
+ * x_train per step.  Supported: L <= 16 with D <= 1023, or L <= 64 with D <= 255.
+ * out_val_loss [1] and out_val_correct [1] are device pointers.
+ * ------------------------------------------------------------------------------------- */
+size_t ddg_learner_workspace_bytes(int D, int L);
+int ddg_learner_train(const float *x_train, const int32_t *y_train, int64_t n_train,
+                      const float *x_valid, const int32_t *y_valid, int64_t n_valid, int D, int L,
+                      int epochs, float lr, float *W, float *b, float *out_val_loss,
+                      int32_t *out_val_correct, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

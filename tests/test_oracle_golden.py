@@ -105,3 +105,15 @@ def test_error_loss():
     z = load("error_loss")
     a, m = orc.error_loss_coded(z["imputed"], z["ori"], z["data_m"], z["continuous_cols"].tolist())
     assert abs(a - float(z["armse"])) < 1e-12 and abs(m - float(z["amae"])) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["learner_small", "learner_wide", "learner_manyclass"])
+def test_learner_oracle_matches_reference(name):
+    """8(f) row 1: the oracle's explicit-gradient restatement of train_L_code against the reference's outputs."""
+    z = load(name)
+    T = torch.tensor
+    loss, acc, W, b = orc.learner_train(int(z["epoch"]), T(z["x_train"]), T(z["y_train"]), T(z["x_valid"]),
+                                        T(z["y_valid"]), int(z["L"]))
+    assert abs(loss - float(z["val_loss"])) < 2e-6
+    assert acc == float(z["acc"])
+    np.testing.assert_allclose(W.numpy(), z["W"], rtol=0, atol=1e-6)
