@@ -15,7 +15,8 @@
 #include "common.h"
 
 #define LRN_NT 256
-#define LRN_BLOCKS 1024               // persistent workgroups of the step kernel (4 per CU)
+#define LRN_BLOCKS 1536               // persistent workgroups of the step kernel (6 per CU)
+#define LRN_LDS_TARGET (26 * 1024)    // LDS per workgroup aimed at, so that 6 workgroups share a CU (latency hiding)
 
 struct LrnArgs {
     const float *x;
@@ -38,12 +39,12 @@ __device__ __forceinline__ LrnLds lrn_carve(float *base, int D, int L, int R) {
     LrnLds s;
     s.ws = (D + 1) | 1;
     s.w = base;
-    s.x = s.w + (size_t)L * s.ws;
+    s.x = s.w + (((size_t)L * s.ws + 3) & ~(size_t)3);
     s.z = s.x + (size_t)R * D;
     return s;
 }
 static inline size_t lrn_lds_bytes(int D, int L, int R) {
-    return ((size_t)L * ((D + 1) | 1) + (size_t)R * D + (size_t)R * L) * 4;
+    return ((((size_t)L * ((D + 1) | 1) + 3) & ~(size_t)3) + (size_t)R * D + (size_t)R * L) * 4;
 }
 
 __device__ __forceinline__ void lrn_load_weights(const LrnLds &s, const float *W, const float *b, int D, int L) {
@@ -56,16 +57,45 @@ __device__ __forceinline__ void lrn_load_weights(const LrnLds &s, const float *W
 __device__ __forceinline__ void lrn_load_tile(const LrnLds &s, const float *x, int64_t row0, int nr, int D) {
     const float *src = x + row0 * D;
     const int tot = nr * D;
-    for (int i = threadIdx.x; i < tot; i += LRN_NT) s.x[i] = src[i];
+    if (((row0 * D) & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)s.x & 15) == 0) {    // 16-byte path
+        const int tot4 = tot >> 2;
+        for (int i = threadIdx.x; i < tot4; i += LRN_NT)
+            reinterpret_cast<f32x4 *>(s.x)[i] = reinterpret_cast<const f32x4 *>(src)[i];
+        for (int i = (tot4 << 2) + threadIdx.x; i < tot; i += LRN_NT) s.x[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < tot; i += LRN_NT) s.x[i] = src[i];
+    }
 }
-// logits of the tile: thread per (row, class)
+// logits of the tile: 8 threads per row, each over an eighth of the columns for ALL classes (x is read once, the
+// weight reads are broadcasts), then a 3-step butterfly over the 8 partners; rows in passes of LRN_NT / 8
+template <int LCAP>
 __device__ __forceinline__ void lrn_logits(const LrnLds &s, int nr, int D, int L) {
-    for (int i = threadIdx.x; i < nr * L; i += LRN_NT) {
-        const int r = i / L, j = i - r * L;
-        const float *xr = s.x + r * D, *wj = s.w + j * s.ws;
-        float a = wj[D];
-        for (int d = 0; d < D; ++d) a = fmaf(xr[d], wj[d], a);
-        s.z[r * L + j] = a;
+    const int q = threadIdx.x & 7;
+    const int dq = (D + 7) >> 3;
+    const int d0 = q * dq, d1 = (d0 + dq < D) ? d0 + dq : D;
+    for (int r0 = 0; r0 < nr; r0 += LRN_NT / 8) {
+        const int r = r0 + (threadIdx.x >> 3);
+        float a[LCAP];
+#pragma unroll
+        for (int j = 0; j < LCAP; ++j) a[j] = 0.f;
+        if (r < nr) {
+            const float *xr = s.x + r * D;
+            for (int d = d0; d < d1; ++d) {
+                const float xv = xr[d];
+#pragma unroll
+                for (int j = 0; j < LCAP; ++j)
+                    if (j < L) a[j] = fmaf(xv, s.w[j * s.ws + d], a[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LCAP; ++j)
+            if (j < L) {
+                float v = a[j];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                if (q == 0 && r < nr) s.z[r * L + j] = v + s.w[j * s.ws + D];
+            }
     }
 }
 
@@ -87,7 +117,7 @@ __global__ __launch_bounds__(LRN_NT) void k_learner_step(LrnArgs p) {
         __syncthreads();                       // previous tile fully consumed (and the weights are in place)
         lrn_load_tile(s, p.x, row0, nr, D);
         __syncthreads();
-        lrn_logits(s, nr, D, L);
+        lrn_logits<LCAP>(s, nr, D, L);
         __syncthreads();
         if ((int)threadIdx.x < nr) {           // one thread per row: both softmaxes and the logit gradient
             float *z = s.z + threadIdx.x * L;
@@ -136,19 +166,33 @@ __global__ __launch_bounds__(LRN_NT) void k_learner_step(LrnArgs p) {
     }
 }
 
-// W[j][d] -= lr * sum_blocks partial[block][j][d]   (fixed order, fp64 accumulation)
-__global__ void k_learner_apply(const float *__restrict__ partial, int nblocks, int D, int L, float lr,
-                                float *__restrict__ W, float *__restrict__ b) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L * (D + 1)) return;
+// W[j][d] -= lr * sum_blocks partial[block][j][d].  Workgroup = 16 outputs x 16 segments of the block range; every
+// segment is summed in order (fp64), the 16 segment sums are added in order: bitwise reproducible.
+__global__ __launch_bounds__(256) void k_learner_apply(const float *__restrict__ partial, int nblocks, int D, int L,
+                                                       float lr, float *__restrict__ W, float *__restrict__ b) {
+    __shared__ double seg[16][17];
+    const int o = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    const int tot = L * (D + 1);
+    const int per = (nblocks + 15) / 16;
+    const int g0 = sg * per, g1 = g0 + per < nblocks ? g0 + per : nblocks;
     double a = 0.0;
-    for (int g = 0; g < nblocks; ++g) a += (double)partial[(int64_t)g * L * (D + 1) + i];
-    const int j = i / (D + 1), d = i - j * (D + 1);
-    const float upd = lr * (float)a;
-    if (d < D) W[(int64_t)j * D + d] -= upd; else b[j] -= upd;
+    if (i < tot)
+        for (int g = g0; g < g1; ++g) a += (double)partial[(int64_t)g * tot + i];
+    seg[sg][o] = a;
+    __syncthreads();
+    if (sg == 0 && i < tot) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += seg[k][o];
+        const int j = i / (D + 1), d = i - j * (D + 1);
+        const float upd = lr * (float)t;
+        if (d < D) W[(int64_t)j * D + d] -= upd; else b[j] -= upd;
+    }
 }
 
 // validation: per workgroup sum of (logsumexp(p) - p[y]) and count of argmax(p) == y
+template <int LCAP>
 __global__ __launch_bounds__(LRN_NT) void k_learner_eval(LrnArgs p, double *__restrict__ loss_part,
                                                          int32_t *__restrict__ hit_part) {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
@@ -166,7 +210,7 @@ __global__ __launch_bounds__(LRN_NT) void k_learner_eval(LrnArgs p, double *__re
         __syncthreads();
         lrn_load_tile(s, p.x, row0, nr, D);
         __syncthreads();
-        lrn_logits(s, nr, D, L);
+        lrn_logits<LCAP>(s, nr, D, L);
         __syncthreads();
         if ((int)threadIdx.x < nr) {
             const float *z = s.z + threadIdx.x * L;
@@ -211,7 +255,10 @@ __global__ void k_learner_eval_finish(const double *__restrict__ loss_part, cons
 // ---------------------------------------------------------------------------------------------
 static inline size_t lrn_al(size_t x) { return (x + 255) & ~(size_t)255; }
 static int lrn_rows_per_tile(int D, int L) {
+    // the largest power of two that keeps the workgroup near LRN_LDS_TARGET; wide tables fall back to what fits at all
     for (int R = LRN_NT; R >= 8; R >>= 1)
+        if (lrn_lds_bytes(D, L, R) <= LRN_LDS_TARGET) return R;
+    for (int R = 64; R >= 8; R >>= 1)
         if (lrn_lds_bytes(D, L, R) <= 150 * 1024) return R;
     return 0;
 }
@@ -264,7 +311,7 @@ extern "C" int ddg_learner_train(const float *x_train, const int32_t *y_train, i
     const int64_t ntiles = (n_train + R - 1) / R;
     const int grid = (int)(ntiles < LRN_BLOCKS ? ntiles : LRN_BLOCKS);
     const int DMn = (D + 1 + LRN_NT - 1) / LRN_NT;
-    const int napply = (L * (D + 1) + 255) / 256;
+    const int napply = (L * (D + 1) + 15) / 16;
     for (int e = 0; e < epochs; ++e) {
         if (L <= 4 && DMn == 1) rc = lrn_launch_step<4, 1>(a, grid, lds, s);
         else if (L <= 16 && DMn == 1) rc = lrn_launch_step<16, 1>(a, grid, lds, s);
@@ -280,13 +327,16 @@ extern "C" int ddg_learner_train(const float *x_train, const int32_t *y_train, i
     v.x = x_valid; v.y = y_valid; v.n = n_valid; v.partial = nullptr;
     const int64_t vt = (n_valid + R - 1) / R;
     const int vgrid = (int)(vt < LRN_BLOCKS ? vt : LRN_BLOCKS);
-    static size_t granted_eval = 48 * 1024;
-    if (lds > granted_eval) {
-        if (hipFuncSetAttribute((const void *)k_learner_eval, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DDG_E_LAUNCH;
-        granted_eval = lds;
+    static size_t granted_eval[3] = {48 * 1024, 48 * 1024, 48 * 1024};
+    const int ev = L <= 4 ? 0 : (L <= 16 ? 1 : 2);
+    const void *evf = ev == 0 ? (const void *)k_learner_eval<4> : ev == 1 ? (const void *)k_learner_eval<16> : (const void *)k_learner_eval<64>;
+    if (lds > granted_eval[ev]) {
+        if (hipFuncSetAttribute(evf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DDG_E_LAUNCH;
+        granted_eval[ev] = lds;
     }
-    k_learner_eval<<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
+    if (ev == 0) k_learner_eval<4><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
+    else if (ev == 1) k_learner_eval<16><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
+    else k_learner_eval<64><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
     k_learner_eval_finish<<<1, 64, 0, s>>>(loss_part, hit_part, vgrid, n_valid, out_val_loss, out_val_correct);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
