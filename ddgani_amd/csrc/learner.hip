@@ -313,11 +313,13 @@ extern "C" int ddg_learner_train(const float *x_train, const int32_t *y_train, i
     const int DMn = (D + 1 + LRN_NT - 1) / LRN_NT;
     const int napply = (L * (D + 1) + 15) / 16;
     for (int e = 0; e < epochs; ++e) {
-        if (L <= 4 && DMn == 1) rc = lrn_launch_step<4, 1>(a, grid, lds, s);
-        else if (L <= 16 && DMn == 1) rc = lrn_launch_step<16, 1>(a, grid, lds, s);
-        else if (L <= 16 && DMn == 2) rc = lrn_launch_step<16, 2>(a, grid, lds, s);
-        else if (L <= 16) rc = lrn_launch_step<16, 4>(a, grid, lds, s);
-        else rc = lrn_launch_step<64, 1>(a, grid, lds, s);
+#define LRN_CASE(LC, DMC) rc = lrn_launch_step<LC, DMC>(a, grid, lds, s)
+        const int dm = DMn <= 1 ? 1 : (DMn == 2 ? 2 : 4);
+        if (L > 16) LRN_CASE(64, 1);
+        else if (L <= 4) { if (dm == 1) LRN_CASE(4, 1); else if (dm == 2) LRN_CASE(4, 2); else LRN_CASE(4, 4); }
+        else if (L <= 8) { if (dm == 1) LRN_CASE(8, 1); else if (dm == 2) LRN_CASE(8, 2); else LRN_CASE(8, 4); }
+        else { if (dm == 1) LRN_CASE(16, 1); else if (dm == 2) LRN_CASE(16, 2); else LRN_CASE(16, 4); }
+#undef LRN_CASE
         if (rc) return rc;
         k_learner_apply<<<napply, 256, 0, s>>>(partial, grid, D, L, lr, W, b);
     }
@@ -328,13 +330,13 @@ extern "C" int ddg_learner_train(const float *x_train, const int32_t *y_train, i
     const int64_t vt = (n_valid + R - 1) / R;
     const int vgrid = (int)(vt < LRN_BLOCKS ? vt : LRN_BLOCKS);
     static size_t granted_eval[3] = {48 * 1024, 48 * 1024, 48 * 1024};
-    const int ev = L <= 4 ? 0 : (L <= 16 ? 1 : 2);
-    const void *evf = ev == 0 ? (const void *)k_learner_eval<4> : ev == 1 ? (const void *)k_learner_eval<16> : (const void *)k_learner_eval<64>;
+    const int ev = L <= 8 ? 0 : (L <= 16 ? 1 : 2);
+    const void *evf = ev == 0 ? (const void *)k_learner_eval<8> : ev == 1 ? (const void *)k_learner_eval<16> : (const void *)k_learner_eval<64>;
     if (lds > granted_eval[ev]) {
         if (hipFuncSetAttribute(evf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DDG_E_LAUNCH;
         granted_eval[ev] = lds;
     }
-    if (ev == 0) k_learner_eval<4><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
+    if (ev == 0) k_learner_eval<8><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
     else if (ev == 1) k_learner_eval<16><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
     else k_learner_eval<64><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
     k_learner_eval_finish<<<1, 64, 0, s>>>(loss_part, hit_part, vgrid, n_valid, out_val_loss, out_val_correct);
