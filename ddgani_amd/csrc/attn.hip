@@ -869,42 +869,52 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_rescore(AttnArgs p) {
         }
         const int mykidx = has ? kl[mypos] : 0;
         float mysv = -INFINITY;
-        unsigned long long bal = __ballot(has);
-        while (bal) {
+        // Four queries per batch, one per 16-lane group; a group scores the candidates of BOTH lanes of its query
+        // (lane r and lane r + 32) against one load of the query row.
+        const unsigned long long bal = __ballot(has);
+        unsigned qm = (unsigned)bal | (unsigned)(bal >> 32);
+        while (qm) {
             int src[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 src[j] = -1;
-                if (bal) { src[j] = __ffsll((long long)bal) - 1; bal &= bal - 1; }
+                if (qm) { src[j] = __ffs((int)qm) - 1; qm &= qm - 1; }
             }
             const int grp = lane >> 4;
             const int sm = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
             const int smc = sm < 0 ? 0 : sm;
-            int kidx = __shfl(mykidx, smc);
+            int ka = __shfl(mykidx, smc);
+            int kb = __shfl(mykidx, smc + 32);
             int qr = __shfl(qrow, smc);
-            if (sm < 0) { qr = 0; kidx = 0; }             // idle group: loads row 0, result ignored
+            if (sm < 0) { qr = 0; ka = 0; kb = 0; }       // idle group: loads row 0, results ignored (lanes without a
+                                                          // candidate hold key index 0 as well)
             const float *xq = p.Xqp + (int64_t)qr * DP + KS * (lane & 15);
-            const float *xk = p.Xkp + (int64_t)kidx * DP + KS * (lane & 15);
-            f32x4 xqv[KS / 4], xkv[KS / 4];
+            const float *xa = p.Xkp + (int64_t)ka * DP + KS * (lane & 15);
+            const float *xb = p.Xkp + (int64_t)kb * DP + KS * (lane & 15);
+            f32x4 qw[KS / 4], xav[KS / 4], xbv[KS / 4];
 #pragma unroll
             for (int i = 0; i < KS / 4; ++i) {
-                xqv[i] = *reinterpret_cast<const f32x4 *>(xq + 4 * i);
-                xkv[i] = *reinterpret_cast<const f32x4 *>(xk + 4 * i);
+                qw[i] = *reinterpret_cast<const f32x4 *>(xq + 4 * i);
+                xav[i] = *reinterpret_cast<const f32x4 *>(xa + 4 * i);
+                xbv[i] = *reinterpret_cast<const f32x4 *>(xb + 4 * i);
             }
-            float part = 0.f;
+            float pa = 0.f, pb = 0.f;
 #pragma unroll
             for (int i = 0; i < KS / 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) part = fmaf(wreg[i][e] * xqv[i][e], xkv[i][e], part);
-            const float sv = row16_sum(part);
-            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 0));
-            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 16));
-            const float s2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 32));
-            const float s3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sv), 48));
-            if (lane == src[0]) mysv = s0;
-            if (lane == src[1]) mysv = s1;
-            if (lane == src[2]) mysv = s2;
-            if (lane == src[3]) mysv = s3;
+                for (int e = 0; e < 4; ++e) {
+                    const float q = wreg[i][e] * qw[i][e];
+                    pa = fmaf(q, xav[i][e], pa);
+                    pb = fmaf(q, xbv[i][e], pb);
+                }
+            const float sva = row16_sum(pa), svb = row16_sum(pb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float aj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(sva), 16 * j));
+                const float bj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__float_as_int(svb), 16 * j));
+                if (has && lane == src[j]) mysv = aj;
+                if (has && src[j] >= 0 && lane == src[j] + 32) mysv = bj;
+            }
         }
 #ifdef FILT_STATS
         if (has) atomicAdd(&g_filt_stats[0], 1ull);
