@@ -625,9 +625,13 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
 #ifdef FILT_NOCOLLECT      // timing experiments only (wrong results): what this path costs
         ++ncand; return;
 #endif
+        // bit g = sign of (threshold - logit g): one subtract and one v_alignbit per logit, no compare / select
+        // chain through vcc (logit 15 first, so that logit g ends at bit g)
         unsigned cm = 0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) cm |= (acc[g] > thr_adj) ? (1u << g) : 0u;
+        for (int g = 15; g >= 0; --g)
+            cm = __builtin_amdgcn_alignbit(cm, __float_as_uint(thr_adj - acc[g]), 31);
+        cm &= 0xffffu;
         if (cm) {
             if (ncand < FILT_CAPH) cand[ncand * FILT_NT] = (int32_t)(((unsigned)tile << 16) | cm);
             ++ncand;
