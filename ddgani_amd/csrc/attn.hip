@@ -445,7 +445,6 @@ extern "C" int ddg_debug_filt_stats(unsigned long long *out4, int reset) {
 #endif
 #define FILT_NT (64 * FILT_NW)        // threads per workgroup
 #define QPBF (32 * FILT_NW)           // queries per workgroup
-#define TKF (16 * FILT_NW)            // keys per stage
 #define FILT_EPS 8.0e-3f
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -485,7 +484,6 @@ __device__ __forceinline__ void set_wave_prio(int pr) {      // s_setprio takes 
 // ---- screening pass over one chunk of the key lists: bf16 MFMA logits against the threshold each query
 // had when the chunk started; the key-list positions of everything that may reach the top-(k+1) are
 // appended to the lane's candidate slots.  No exact arithmetic, no lists: a pure MFMA stream.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // x * M for the small constants the row stride needs, without the quarter-rate 32-bit multiply
 template <int M>
 __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
