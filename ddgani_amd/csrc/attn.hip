@@ -27,6 +27,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
+#include <type_traits>
 
 #define QPB 128          // queries per block
 #define TK 32            // keys per tile
@@ -496,7 +497,7 @@ __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
     }
 }
 // keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
-__host__ __device__ constexpr int screen_stage_keys(int KS) { return (FILT_NW == 8 && KS <= 12) ? 128 : 64; }
+__host__ __device__ constexpr int screen_stage_keys(int KS) { return FILT_NW != 8 ? 64 : (KS <= 12 ? 128 : 96); }
 template <int KS>
 __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     // fragment reads were issued before the barrier of stage t-1 and consumed a whole stage ago.
     constexpr int H = KS / 2;
     constexpr int NT_STAGE = TKS / 32;
-    static_assert(NPF <= H && NT_STAGE >= 2 && NT_STAGE % 2 == 0, "slot plan");
+    static_assert(NPF <= H && NT_STAGE >= 2 && FILT_SIG_J < 2 * NT_STAGE - 1, "slot plan");
     const int nst = (key_hi - key_lo + TKS - 1) / TKS;
     load_idx(0);
     row_offsets(krow);
@@ -690,8 +691,10 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     unsigned long long tm_bar = 0, tm_coll = 0, tm_vm = 0, tm_ct = 0, ts_begin = TSTAMP();
 #endif
     int b_cur = 0, b_nxt = 1;
-#pragma unroll 1
-    for (int t = 0; t < nst; ++t) {
+    // one stage; PAR = parity of the stage's first tile (the two accumulator sets alternate per tile, and a stage of
+    // an odd number of tiles flips the parity: the loop below then runs stages in pairs)
+    auto stage_body = [&](auto parc, int t) {
+        constexpr int PAR = decltype(parc)::value;
         const char *base = kbuf(b_cur);
         const char *base_n = kbuf(b_nxt);
         const int b_nn = 3 - b_cur - b_nxt;
@@ -708,9 +711,9 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 for (int i = 0; i < H; ++i) {
                     if (u == 0 && i == 0) {
 #pragma unroll
-                        for (int g = 0; g < 16; ++g) cacc[s & 1][g] = 0.f;
+                        for (int g = 0; g < 16; ++g) cacc[(s + PAR) & 1][g] = 0.f;
                     }
-                    cacc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[u * H + i], cacc[s & 1], 0, 0, 0);
+                    cacc[(s + PAR) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[u * H + i], cacc[(s + PAR) & 1], 0, 0, 0);
                     if (j + 1 < 2 * NT_STAGE)
                         fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
                     else
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
 #pragma unroll
                         for (int o = 0; o < 8; ++o)
-                            if (o * H / 8 == i) max_op(cacc[(s + 1) & 1], mx[(s + 1) & 1], o);
+                            if (o * H / 8 == i) max_op(cacc[(s + 1 + PAR) & 1], mx[(s + 1 + PAR) & 1], o);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -742,7 +745,13 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 }
                 if (j == 2 * NT_STAGE - 2) {
                     const unsigned target = (unsigned)FILT_NW * (unsigned)(t + 1);
+#ifdef FILT_TIMING
+                    const unsigned long long tb0 = TSTAMP();
+#endif
                     while (__builtin_amdgcn_readfirstlane(*(volatile unsigned *)&s_sync) < target) __builtin_amdgcn_s_sleep(1);
+#ifdef FILT_TIMING
+                    tm_bar += TSTAMP() - tb0;
+#endif
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -765,14 +774,14 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
 #endif
             }
             if (s > 0 || t > 0) {                        // the tile before this one (s == 0: the previous stage's last)
-                if (__builtin_amdgcn_ballot_w64(mx[(s + 1) & 1] > thr_adj) != 0) {
+                if (__builtin_amdgcn_ballot_w64(mx[(s + 1 + PAR) & 1] > thr_adj) != 0) {
 #ifdef FILT_TIMING
                     ++tm_coll;
                     const unsigned long long tc0 = TSTAMP();
-                    collect(cacc[(s + 1) & 1], t * NT_STAGE + s - 1);
+                    collect(cacc[(s + 1 + PAR) & 1], t * NT_STAGE + s - 1);
                     tm_ct += TSTAMP() - tc0;
 #else
-                    collect(cacc[(s + 1) & 1], t * NT_STAGE + s - 1);
+                    collect(cacc[(s + 1 + PAR) & 1], t * NT_STAGE + s - 1);
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -780,16 +789,26 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         }
         b_cur = b_nxt;
         b_nxt = b_nn;
+    };
+    if constexpr (NT_STAGE % 2 == 0) {
+#pragma unroll 1
+        for (int t = 0; t < nst; ++t) stage_body(std::integral_constant<int, 0>{}, t);
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < nst; t += 2) {
+            stage_body(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < nst) stage_body(std::integral_constant<int, 1>{}, t + 1);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the stages past the end must not outlive the wave
     set_wave_prio(0);
-    {                                                    // last tile of the chunk
-        const f32x16 &pa = cacc[(NT_STAGE - 1) & 1];
+    auto last_tile = [&](const f32x16 &pa) {             // last tile of the chunk
         float m = 0.f;
 #pragma unroll
         for (int o = 0; o < 8; ++o) max_op(pa, m, o);
         if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0) collect(pa, nst * NT_STAGE - 1);
-    }
+    };
+    if ((nst * NT_STAGE - 1) & 1) last_tile(cacc[1]); else last_tile(cacc[0]);
 #ifdef FILT_TIMING
     if (lane == 0) {
         atomicAdd(&g_filt_time[2], tm_bar); atomicAdd(&g_filt_time[3], (unsigned long long)nst);
