@@ -497,7 +497,9 @@ __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
     }
 }
 // keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
-__host__ __device__ constexpr int screen_stage_keys(int KS) { return FILT_NW != 8 ? 64 : (KS <= 12 ? 128 : 96); }
+__host__ __device__ constexpr int screen_stage_keys(int KS) {
+    return FILT_NW != 8 ? 64 : (KS <= 4 ? 256 : KS <= 8 ? 192 : KS <= 12 ? 128 : 96);     // 96 ... 147 KB for three buffers
+}
 template <int KS>
 __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int DP = KS * 16;
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     // fragment reads were issued before the barrier of stage t-1 and consumed a whole stage ago.
     constexpr int H = KS / 2;
     constexpr int NT_STAGE = TKS / 32;
-    static_assert(NPF <= H && NT_STAGE >= 2 && FILT_SIG_J < 2 * NT_STAGE - 1, "slot plan");
+    static_assert(NT_STAGE >= 2 && FILT_SIG_J < 2 * NT_STAGE - 1, "slot plan");
     const int nst = (key_hi - key_lo + TKS - 1) / TKS;
     load_idx(0);
     row_offsets(krow);
@@ -719,9 +721,15 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     else
                         fr[0][i] = frag(base_n, 0, i);
                     if (j == 0 && i == 0) load_idx(t + 2);        // key-list indices of stage t+2
-                    if (j == 2 * NT_STAGE - 2 && i < NPF)
-                        krow[i] = mul_small<KS>((uint32_t)__builtin_amdgcn_ds_bpermute(urow4[i], kix));
-                    if (j == 2 * NT_STAGE - 1 && i < NPF) dma_piece(b_nn, i);   // key rows of stage t+2
+                    if (j == 2 * NT_STAGE - 2) {
+#pragma unroll
+                        for (int e = i; e < NPF; e += H)
+                            krow[e] = mul_small<KS>((uint32_t)__builtin_amdgcn_ds_bpermute(urow4[e], kix));
+                    }
+                    if (j == 2 * NT_STAGE - 1) {                  // key rows of stage t+2
+#pragma unroll
+                        for (int e = i; e < NPF; e += H) dma_piece(b_nn, e);
+                    }
                     if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
 #pragma unroll
                         for (int o = 0; o < 8; ++o)
