@@ -252,6 +252,9 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
     int64_t gx = ntiles;
     const int64_t cap = (256 * 2 + ncol - 1) / ncol;   // ~2 resident blocks per CU in total
     if (gx > cap) gx = cap;
+    // workgroup (x, y) has linear id x + y * gx and lands on XCD id % 8: with gx a multiple of 8 the column tiles of a
+    // row tile share an XCD, so the A rows come from HBM once and from that XCD's L2 for the other column tiles
+    if (gx >= 8) gx -= gx % 8;
     dim3 grid((unsigned)gx, (unsigned)ncol);
     switch (prologue) {
         case DDG_PRO_NONE: k_linear<DDG_PRO_NONE><<<grid, 256, 0, s>>>(p); break;
