@@ -68,6 +68,9 @@ SIGNATURES = {
     "ddg_denoiser_fwd": (C.c_int, [C.POINTER(GenWeights), c_f32p, c_i64p, C.c_int, c_u8p, c_u8p, c_u8p, C.c_float,
                                    C.c_uint64, C.c_uint64, C.c_float, c_i32p, c_u8p, C.c_int, C.c_int, c_f32p,
                                    C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_denoiser_fwd_static": (C.c_int, [C.POINTER(GenWeights), c_f32p, c_i64p, C.c_int, c_u8p, c_u8p, c_u8p, C.c_float,
+                                          C.c_uint64, C.c_uint64, C.c_float, c_i32p, c_u8p, C.c_int, C.c_int, c_f32p,
+                                          C.c_int64, C.c_void_p]),
     "ddg_disc_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "ddg_disc_fwd": (C.c_int, [C.POINTER(DiscWeights), c_f32p, c_f32p, c_i64p, C.c_int, c_f32p, C.c_int64,
                                C.c_void_p, C.c_size_t, C.c_void_p]),

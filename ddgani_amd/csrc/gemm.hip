@@ -13,6 +13,7 @@
 // is one 16-byte LDS read; A and B use the same permutation, so the dot products are unchanged
 // up to fp32 summation order.
 #include "common.h"
+#include <mutex>
 
 #define BM 128
 #define BN 128
@@ -346,6 +347,60 @@ extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, cons
         if (rc) return rc;
     }
     return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ddg_denoiser_fwd_static: ddg_denoiser_fwd for callers that cannot allocate or bring a workspace
+// (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+// in the reference.  The layer activations z1 / z2, the fp64 BatchNorm sums and the scale / shift
+// vectors live in a file-scope device array of DDG_STATIC_SCRATCH_BYTES; every GPU holds its own copy
+// at its own address until the process ends.  The array's name is only a host-side handle:
+// its device address is looked up once per device with hipGetSymbolAddress and that pointer is what
+// the kernels and hipMemsetAsync receive.  Calls that overlap on one GPU share the array and race.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[DDG_STATIC_SCRATCH_BYTES];
+#define DDG_MAX_DEVICES 64
+static void *g_scratch_ptr[DDG_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int static_scratch(void **out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DDG_MAX_DEVICES) return DDG_E_LAUNCH;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));     // address on the CURRENT device
+        if (e != hipSuccess || !ptr) {
+            fprintf(stderr, "ddgani: hipGetSymbolAddress(scratch) on device %d: %s\n", dev, hipGetErrorString(e));
+            return DDG_E_LAUNCH;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return DDG_OK;
+}
+
+extern "C" int ddg_denoiser_fwd_static(const ddg_gen_weights *w, const float *x_t, const int64_t *t, int t_uniform,
+                                       const uint8_t *drop0, const uint8_t *drop1, const uint8_t *drop2, float drop_p,
+                                       uint64_t seed, uint64_t stream_id, float bn_eps, const int32_t *offsets,
+                                       const uint8_t *is_cat, int C, int apply_head, float *out, int64_t rows,
+                                       void *stream) {
+    if (!w || !x_t || !out || rows < 1) return DDG_E_ARG;
+    if (w->in_dim < 1 || w->enc_dim < 1 || w->lat_dim < 1) return DDG_E_ARG;
+    const size_t need = ddg_denoiser_workspace_bytes(rows, w->in_dim, w->enc_dim, w->lat_dim);
+    if (need > (size_t)DDG_STATIC_SCRATCH_BYTES) {
+        fprintf(stderr, "ddgani: ddg_denoiser_fwd_static: %lld rows x (%d + %d) columns need %zu bytes of scratch, the "
+                        "static array holds %zu; use ddg_denoiser_fwd with a workspace\n",
+                (long long)rows, w->enc_dim, w->lat_dim, need, (size_t)DDG_STATIC_SCRATCH_BYTES);
+        return DDG_E_SCRATCH_LIMIT;
+    }
+    void *ptr = nullptr;
+    int rc = static_scratch(&ptr);
+    if (rc) return rc;
+    // the BatchNorm sums must start at zero: ddg_denoiser_fwd clears them (hipMemsetAsync on `ptr`) on every call;
+    // everything else in the array is written before it is read
+    return ddg_denoiser_fwd(w, x_t, t, t_uniform, drop0, drop1, drop2, drop_p, seed, stream_id, bn_eps, offsets, is_cat,
+                            C, apply_head, out, rows, ptr, (size_t)DDG_STATIC_SCRATCH_BYTES, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -233,6 +233,25 @@ def denoiser_fwd(P: GenParams, x_t, t, layout: FieldLayout, drops=None, drop_p: 
     return out
 
 
+def denoiser_fwd_static(P: GenParams, x_t, t, layout: FieldLayout, drops=None, drop_p: float = 0.2, seed: int = 0,
+                        stream_id: int = 0, bn_eps: float = 1e-5, apply_head: bool = True, out=None):
+    """ddg_denoiser_fwd_static: the denoiser forward without a workspace (static device scratch, no allocation
+    inside the library; ``out`` should be passed by callers that must not allocate at all)."""
+    rows = x_t.shape[0]
+    off, cat = layout.on(x_t.device)
+    if out is None:
+        out = torch.empty_like(x_t)
+    if isinstance(t, torch.Tensor):
+        tp, tu = _ptr(t, torch.int64), 0
+    else:
+        tp, tu = None, int(t)
+    d = [None, None, None] if drops is None else [_ptr(m, torch.uint8) for m in drops]
+    check(lib().ddg_denoiser_fwd_static(C.byref(P.c), _ptr(x_t, torch.float32), tp, tu, d[0], d[1], d[2],
+                                        float(drop_p), seed, stream_id, bn_eps, _ptr(off), _ptr(cat), layout.C,
+                                        int(apply_head), _ptr(out), rows, _stream()), "ddg_denoiser_fwd_static")
+    return out
+
+
 def disc_fwd(P: DiscParams, xtj1, xt, t, out=None):
     rows = xt.shape[0]
     nb = lib().ddg_disc_workspace_bytes(rows, P.lat_dim)

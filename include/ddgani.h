@@ -35,6 +35,7 @@ extern "C" {
 #define DDG_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for               */
 #define DDG_E_WORKSPACE (-3)  /* workspace too small                                        */
 #define DDG_E_LAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch             */
+#define DDG_E_SCRATCH_LIMIT (-5) /* input larger than the static scratch of a *_static entry point */
 
 #define DDG_MAX_D 256         /* widest encoded table the attention kernels are built for   */
 #define DDG_MAX_TOPK_REG 30   /* absolute k up to this uses the in-register selection       */
@@ -150,6 +151,25 @@ int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, const int64_t *
                      uint64_t seed, uint64_t stream_id, float bn_eps,
                      const int32_t *offsets, const uint8_t *is_cat, int C, int apply_head,
                      float *out, int64_t rows, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ddg_denoiser_fwd_static: NO COUNTERPART IN THE REFERENCE.  ddg_denoiser_fwd for callers that
+ * cannot allocate device memory or carry a workspace: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same arguments and results as ddg_denoiser_fwd minus the
+ * workspace; the layer activations and BatchNorm sums live in a static device array of
+ * DDG_STATIC_SCRATCH_BYTES that each GPU keeps until the process ends.  It allocates nothing.
+ * rows is limited by ddg_denoiser_workspace_bytes(rows, in, enc, lat) <= DDG_STATIC_SCRATCH_BYTES
+ * (about 15 800 rows at D = 176); larger inputs return DDG_E_SCRATCH_LIMIT.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.  The first
+ * call on a device looks up the array's device address (hipGetSymbolAddress); make it outside a
+ * graph capture.
+ * ------------------------------------------------------------------------------------- */
+#define DDG_STATIC_SCRATCH_BYTES (32u << 20)
+int ddg_denoiser_fwd_static(const ddg_gen_weights *w, const float *x_t, const int64_t *t, int t_uniform,
+                            const uint8_t *drop0, const uint8_t *drop1, const uint8_t *drop2, float drop_p,
+                            uint64_t seed, uint64_t stream_id, float bn_eps,
+                            const int32_t *offsets, const uint8_t *is_cat, int C, int apply_head,
+                            float *out, int64_t rows, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * a10  Discriminator_noise_x.forward        model/Discriminator_model.py:82-115
