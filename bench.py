@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                      "multi-rank path on a one-GPU box together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
-    ap.add_argument("--cpu-rows", type=int, default=2048, help="sample rows for the CPU attention-fill timing")
+    ap.add_argument("--cpu-rows", type=int, default=8192, help="sample rows for the CPU attention-fill timing")
     return ap.parse_args()
 
 
@@ -50,8 +50,12 @@ def cpu_baseline(tab_cfg, lay_widths, k_frac_rows, T, D, N_full, sample_rows):
     N); the sampler is O(N) and timed on 100k rows."""
     import numpy as np
     from oracle import ddgani_oracle as orc
+    # SURVEY 8(d): all host cores.  On the GPU pool os.cpu_count() reports the whole machine while a one-GPU lease owns
+    # 16 of its cores (OMP_NUM_THREADS is set to that share), so the share is what "all cores" means there.
     cores = os.cpu_count() or 1
-    cores = min(cores, 16)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if share > 0:
+        cores = min(cores, share)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
     offsets = [0]
@@ -113,9 +117,30 @@ def pmc_traffic(workload, rows, kernel_prefix):
     return None, None
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` from a plain shell: start N ranks (one per GPU) with torch.distributed.run as a CHILD
+    process -- before this process has touched the GPU -- relay rank 0's JSON line and exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")          # torch.distributed.run would otherwise force 1 (cpu_baseline leg)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.one_device:
@@ -200,10 +225,18 @@ def main():
         step(a.warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        cdev = dev if a.backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        one = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)         # ranks that actually ran the timed loop
+        ranks_seen = int(one.item())
+        if ranks_seen != a.gpus:
+            print(f"bench.py: {ranks_seen} ranks took part, --gpus {a.gpus}", file=sys.stderr)
+            sys.exit(3)
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -217,7 +250,7 @@ def main():
         traffic, traffic_src = pmc_traffic(a.workload, N, kname) if world == 1 else (None, None)
         res = {
             "metric": "imputed rows/sec (T-step reverse diffusion + top_k attn fill)",
-            "value": N / (dt / a.steps), "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": N / (dt / a.steps), "unit": "rows/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (bf16 MFMA screening, exact fp32 re-scoring of every candidate)" if filt else "f32",
             "data": "synthetic",

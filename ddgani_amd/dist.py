@@ -79,7 +79,9 @@ def sharded_attn_fill(comm: Comm, backend, X0_local, m_local, W, layout, k: int,
 
 def sharded_denoiser_fwd(comm: Comm, backend, P, x_t, t, layout, N_total: int, drops=None, drop_p: float = 0.2,
                          seed: int = 0, stream_id: int = 0, row_offset: int = 0, bn_eps: float = 1e-5, out=None):
-    """Generator_x0.forward over a row shard with global (sync) BatchNorm statistics."""
+    """Generator_x0.forward over a row shard with global (sync) BatchNorm statistics.  ``stream_id`` must already
+    carry the rank (model.Diffusion.stream_of(..., rank=comm.rank)): on-chip dropout is keyed by the LOCAL element
+    index, so shards need distinct streams."""
     w = P.t
     dev = x_t.device
     d = [None, None, None] if drops is None else drops
@@ -95,27 +97,30 @@ def sharded_denoiser_fwd(comm: Comm, backend, P, x_t, t, layout, N_total: int, d
                                            bn_eps)
         h = z
         pro = backend.PRO_BN_RELU
-        # on-chip dropout is keyed by the element index; offset the stream per rank so shards differ
-        kw = dict(scale=scale, shift=shift, drop=d[l], drop_p=drop_p, seed=seed,
-                  stream_id=(stream_id * 4 + l) * 1024 + comm.rank)
+        kw = dict(scale=scale, shift=shift, drop=d[l], drop_p=drop_p, seed=seed, stream_id=stream_id * 4 + l)
     y = backend.linear(h, w["linears.12.weight"], w["linears.12.bias"], prologue=pro, out=out, **kw)
     return backend.head(y, layout, out=y)
 
 
 def sharded_reverse_sample(comm: Comm, backend, P, T: int, x, M, layout, N_total: int, randomness=None, seed: int = 0,
-                           drop_p: float = 0.2):
-    """T-step reverse diffusion over a row shard (model/Diffusion.py:426-450), sync-BN across ranks."""
+                           drop_p: float = 0.2, call: Optional[int] = None):
+    """T-step reverse diffusion over a row shard (model/Diffusion.py:426-450), sync-BN across ranks.
+    Random streams follow model.Diffusion.stream_of with this rank in the id; every rank must pass the same
+    ``call`` (default: its own next_call(), equal on all ranks when they make the same calls in the same order)."""
+    from .model.Diffusion import KIND_DROP, KIND_EPS, KIND_Z, drop_seed, next_call, stream_of
     r = randomness
-    sid = 1000 * (comm.rank + 1)
-    x_t = backend.forward_noise(x, T, T, eps=None if r is None else r.eps_T, seed=seed, stream_id=sid + 1)
+    call = next_call() if call is None else call
+    rk = comm.rank
+    x_t = backend.forward_noise(x, T, T, eps=None if r is None else r.eps_T, seed=seed,
+                                stream_id=stream_of(call, KIND_EPS, T, rk))
     pred = None
     i = 0
     for ts in range(T, 1, -1):
         pred = sharded_denoiser_fwd(comm, backend, P, x_t, ts, layout, N_total,
-                                    drops=None if r is None else r.drops[i], drop_p=drop_p, seed=seed,
-                                    stream_id=100 + ts)
+                                    drops=None if r is None else r.drops[i], drop_p=drop_p, seed=drop_seed(seed),
+                                    stream_id=stream_of(call, KIND_DROP, ts, rk))
         if ts > 2:
             x_t = backend.reverse_step(x_t, x, M, pred, ts, T, z=None if r is None else r.zs[i], seed=seed,
-                                       stream_id=sid + 200 + ts, out=x_t)
+                                       stream_id=stream_of(call, KIND_Z, ts, rk), out=x_t)
         i += 1
     return pred

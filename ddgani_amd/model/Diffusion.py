@@ -8,6 +8,7 @@ with the reference's ``state_dict`` key layout; all arithmetic happens in the HI
 """
 from __future__ import annotations
 
+import itertools
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -51,27 +52,59 @@ class ExplicitRandomness:
     drops: List[Sequence[torch.Tensor]]
 
 
-def _uniform_t(timestep) -> Optional[int]:
-    if isinstance(timestep, int):
-        return timestep
-    if isinstance(timestep, torch.Tensor) and timestep.numel() > 0:
-        # the sampler passes a constant vector (model/Diffusion.py:432); training passes mixed t
-        return None
-    return None
+# ------------------------------------------------------------------------------------------
+# On-chip random streams.  A Philox stream is (seed, stream_id); the kernels index elements inside it.
+# The reference draws fresh numbers from torch's global generator on every call (randn_like, Dropout),
+# so every call here gets a stream of its own when the caller names none:
+#     stream_id = call << 24 | kind << 20 | rank << 12 | t          (t < 4096, rank < 256, kind < 16)
+# with ``call`` a process-wide monotone counter, ``kind`` what the numbers are for, ``rank`` the shard
+# and ``t`` the timestep.  Dropout (uniform draws) uses a salted SEED as well, so its raw Philox words
+# never coincide with those of a normal stream; ddg_denoiser_fwd appends the layer as stream_id*4 + l.
+# The default seed is torch.initial_seed(): torch.manual_seed() makes a run reproducible, as it does
+# for the reference.
+# ------------------------------------------------------------------------------------------
+KIND_EPS, KIND_Z, KIND_EPS2, KIND_DROP = 1, 2, 3, 4
+MAX_T = 4095
+_DROP_SALT = 0x2545F4914F6CDD1D
+_calls = itertools.count(1)
 
 
-def forward_diffusion(DS: Diffusion_setting, x_0: torch.Tensor, timestep, seed: int = 0, stream_id: int = 0,
-                      eps: Optional[torch.Tensor] = None):
+def next_call() -> int:
+    return next(_calls)
+
+
+def default_seed() -> int:
+    return int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+
+
+def stream_of(call: int, kind: int, t: int = 0, rank: int = 0) -> int:
+    if not (0 <= t <= MAX_T and 0 <= rank < 256 and 0 < kind < 16 and 0 < call < (1 << 36)):
+        raise ValueError(f"random stream out of range: call={call} kind={kind} rank={rank} t={t}")
+    return (call << 24) | (kind << 20) | (rank << 12) | t
+
+
+def drop_seed(seed: int) -> int:
+    return (int(seed) ^ _DROP_SALT) & 0xFFFFFFFFFFFFFFFF
+
+
+def _t_of(timestep) -> int:
+    return int(timestep[0].item()) if isinstance(timestep, torch.Tensor) else int(timestep)
+
+
+def forward_diffusion(DS: Diffusion_setting, x_0: torch.Tensor, timestep, seed: Optional[int] = None,
+                      stream_id: Optional[int] = None, eps: Optional[torch.Tensor] = None):
     """reference: model/Diffusion.py:391-396 -> (x_t, eps).  ``timestep`` may be an int (all rows) or
-    an int64 tensor [rows].  eps=None draws the noise on chip (Philox)."""
+    an int64 tensor [rows].  eps=None draws the noise on chip (Philox): fresh numbers on every call
+    unless the caller names (seed, stream_id)."""
+    seed = default_seed() if seed is None else seed
+    stream_id = stream_of(next_call(), KIND_EPS) if stream_id is None else stream_id
     return ops.forward_noise(x_0, timestep, DS.time_steps, eps=eps, seed=seed, stream_id=stream_id,
                              sched_dev=DS.table, return_eps=True)
 
 
-def get_xt(DS, x_0, timestep, seed: int = 0, stream_id: int = 0, eps=None):
+def get_xt(DS, x_0, timestep, seed: Optional[int] = None, stream_id: Optional[int] = None, eps=None):
     """reference: model/Diffusion.py:398-403."""
-    return ops.forward_noise(x_0, timestep, DS.time_steps, eps=eps, seed=seed, stream_id=stream_id,
-                             sched_dev=DS.table)
+    return forward_diffusion(DS, x_0, timestep, seed=seed, stream_id=stream_id, eps=eps)[0]
 
 
 class Generator_x0(nn.Module):
@@ -93,8 +126,6 @@ class Generator_x0(nn.Module):
         self.time_embedding = nn.Embedding(n_steps, input_dim)
         self.layout = FieldLayout([f.dim() for f in fields])
         self._params = None
-        self.seed = 0
-        self._calls = 0
 
     def device_params(self, refresh: bool = False) -> GenParams:
         dev = self.time_embedding.weight.device
@@ -102,59 +133,73 @@ class Generator_x0(nn.Module):
             self._params = GenParams(self.state_dict(), dev)
         return self._params
 
-    def forward(self, x, t, drops=None):
+    def forward(self, x, t, drops=None, seed: Optional[int] = None, stream_id: Optional[int] = None):
+        """BatchNorm always normalises with the statistics of the batch at hand, as the reference's generator does
+        in every call it ever makes (it is never put in eval mode, model/Diffusion.py:591,595):
+        ``running_mean`` / ``running_var`` are not maintained.  ``eval()`` only switches Dropout off."""
         P = self.device_params(refresh=True)
-        self._calls += 1
+        seed = default_seed() if seed is None else seed
+        stream_id = stream_of(next_call(), KIND_DROP) if stream_id is None else stream_id
         return ops.denoiser_fwd(P, x, t if isinstance(t, int) else t.contiguous(), self.layout, drops=drops,
-                                drop_p=0.2 if self.training else 0.0, seed=self.seed, stream_id=self._calls)
+                                drop_p=0.2 if self.training else 0.0, seed=drop_seed(seed), stream_id=stream_id)
 
 
 # ------------------------------------------------------------------------------------------
-def G_D_onestep(generator_x0, DS, x_t, timestep, M, x, z=None, drops=None, seed: int = 0, stream_id: int = 0):
-    """reference: model/Diffusion.py:412-424.  ``generator_x0`` is a Generator_x0 (this module) or a
-    GenParams; ``timestep`` an int or a constant int64 vector as the reference passes it."""
-    t = int(timestep[0].item()) if isinstance(timestep, torch.Tensor) else int(timestep)
+def G_D_onestep(generator_x0, DS, x_t, timestep, M, x, z=None, drops=None, seed: Optional[int] = None,
+                call: Optional[int] = None):
+    """reference: model/Diffusion.py:412-424.  ``generator_x0`` is a Generator_x0 (this module);
+    ``timestep`` an int or a constant int64 vector as the reference passes it.  z / drops = None draw the
+    noise and the dropout masks on chip, fresh on every call (``call`` = next_call() unless given)."""
+    t = _t_of(timestep)
     if isinstance(generator_x0, GenParams):
         raise TypeError("pass a Generator_x0 module, or use reverse_sample() with GenParams")
-    pred = generator_x0(x_t, t, drops=drops)
-    return ops.reverse_step(x_t, x, M, pred, t, DS.time_steps, z=z, seed=seed, stream_id=stream_id,
+    seed = default_seed() if seed is None else seed
+    call = next_call() if call is None else call
+    pred = generator_x0(x_t, t, drops=drops, seed=seed, stream_id=stream_of(call, KIND_DROP, t))
+    return ops.reverse_step(x_t, x, M, pred, t, DS.time_steps, z=z, seed=seed, stream_id=stream_of(call, KIND_Z, t),
                             sched_host=DS.host)
 
 
 def reverse_sample(P: GenParams, T: int, x: torch.Tensor, M: torch.Tensor, layout: FieldLayout,
-                   randomness: Optional[ExplicitRandomness] = None, seed: int = 0, drop_p: float = 0.2,
-                   sched_host: Optional[np.ndarray] = None) -> torch.Tensor:
+                   randomness: Optional[ExplicitRandomness] = None, seed: Optional[int] = None, drop_p: float = 0.2,
+                   sched_host: Optional[np.ndarray] = None, call: Optional[int] = None) -> torch.Tensor:
     """The T-step reverse diffusion of reverse_diffusion_G_D_sample (model/Diffusion.py:426-450):
     x_T = q(x, T); t = T..3: one generator call + fused reverse step; t = 2: x0_hat = G(x_2, 2).
-    Throughput mode (randomness=None) draws all noise / dropout on chip, keyed by ``seed``."""
+    Throughput mode (randomness=None) draws all noise / dropout on chip: streams (seed, call, kind, t),
+    ``call`` = next_call() unless given (so two passes never share numbers)."""
     sh = ops.schedule(T) if sched_host is None else sched_host
     r = randomness
-    x_t = ops.forward_noise(x, T, T, eps=None if r is None else r.eps_T, seed=seed, stream_id=1)
+    seed = default_seed() if seed is None else seed
+    call = next_call() if call is None else call
+    x_t = ops.forward_noise(x, T, T, eps=None if r is None else r.eps_T, seed=seed, stream_id=stream_of(call, KIND_EPS, T))
     pred = torch.empty_like(x)
     i = 0
     for ts in range(T, 1, -1):
-        ops.denoiser_fwd(P, x_t, ts, layout, drops=None if r is None else r.drops[i], drop_p=drop_p, seed=seed,
-                         stream_id=100 + ts, out=pred)
+        ops.denoiser_fwd(P, x_t, ts, layout, drops=None if r is None else r.drops[i], drop_p=drop_p,
+                         seed=drop_seed(seed), stream_id=stream_of(call, KIND_DROP, ts), out=pred)
         if ts > 2:
             ops.reverse_step(x_t, x, M, pred, ts, T, z=None if r is None else r.zs[i], seed=seed,
-                             stream_id=200 + ts, out=x_t, sched_host=sh)
+                             stream_id=stream_of(call, KIND_Z, ts), out=x_t, sched_host=sh)
         i += 1
     return pred
 
 
 def reverse_diffusion_G_D_sample(generator_x, discriminator_noise_x, DS, timesteps, no, dim, device, x, M_tensor,
-                                 randomness: Optional[ExplicitRandomness] = None, seed: int = 0,
+                                 randomness: Optional[ExplicitRandomness] = None, seed: Optional[int] = None,
                                  eps2: Optional[torch.Tensor] = None):
     """reference: model/Diffusion.py:426-450 -> (x0_hat [N,D], discriminator_out [N,C]).
     The discriminator tail (:442-449) is dead in the reference's default flow but returned for API
     parity; it runs on the GPU here (the reference moves it to the CPU)."""
     P = generator_x.device_params(refresh=True)
+    seed = default_seed() if seed is None else seed
+    call = next_call()
     x0_hat = reverse_sample(P, timesteps, x, M_tensor, generator_x.layout, randomness=randomness, seed=seed,
-                            drop_p=0.2 if generator_x.training else 0.0, sched_host=DS.host)
+                            drop_p=0.2 if generator_x.training else 0.0, sched_host=DS.host, call=call)
     d_out = None
     if discriminator_noise_x is not None:
         from .Discriminator_model import sampler_disc_tail
-        d_out = sampler_disc_tail(discriminator_noise_x, DS, x, x0_hat, eps2=eps2, seed=seed)
+        d_out = sampler_disc_tail(discriminator_noise_x, DS, x, x0_hat, eps2=eps2, seed=seed,
+                                  stream_id=stream_of(call, KIND_EPS2, 2))
     return x0_hat, d_out
 
 
@@ -197,8 +242,7 @@ class ChipRandom:
         self.gen = np.random.default_rng(seed)
 
     def next_stream(self):
-        self.counter += 1
-        return self.counter
+        return next_call()
 
     def batch_indices(self, n_rows, batch):
         return self.gen.choice(n_rows, batch, replace=False, shuffle=False).tolist()
@@ -239,7 +283,8 @@ def _train_batch(rnd, x, M, m_data, T, device, gen_widths):
         eps = rnd.normal(x0.shape[0], x0.shape[1], device)
         drops = rnd.dropout(x0.shape[0], gen_widths, device)
         return x0, Mb, mb, t, dict(eps=eps, drops=drops)
-    return x0, Mb, mb, t, dict(seed=rnd.seed, stream_id=rnd.next_stream())
+    # one stream number for the step: the library derives eps (normal) and the three dropout layers from it
+    return x0, Mb, mb, t, dict(seed=rnd.seed, stream_id=stream_of(rnd.next_stream(), KIND_EPS))
 
 
 def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, loss_scaler, other_loss, epoch,
@@ -355,7 +400,7 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
                                                 sched_host=DS.host)
             else:
                 generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout,
-                                                seed=rnd.seed + 7919 * epoch, sched_host=DS.host)
+                                                seed=rnd.seed, sched_host=DS.host)
             code = ops.mask_merge(x, M_tensor, generator_data, generator_x.layout)      # :598, :606-615
             cur_r, cur_m = test_impute_data_rmse(code, fields, value_cat, values, miss_data_x.copy(), data_m, enc,
                                                  ori_data, continuous_cols)

@@ -57,12 +57,12 @@ class Discriminator_noise_x(nn.Module):
 
 
 def sampler_disc_tail(disc: Discriminator_noise_x, DS, x, x0_hat, eps2: Optional[torch.Tensor] = None,
-                      seed: int = 0):
+                      seed: int = 0, stream_id: int = 300):
     """The t=2 tail of the reference sampler (model/Diffusion.py:442-447): X_2 = q(x,2;eps2);
     x_1 = posterior mean(x0_hat, X_2) + std*eps2 where the reference's ``std`` already contains eps2
     (so the noise enters squared, :443-445); D(x_1, X_2, 2).  A reverse step with M=0 and z=eps2^2
     is exactly that expression."""
     T = DS.time_steps
-    X_t, e = ops.forward_noise(x, 2, T, eps=eps2, seed=seed, stream_id=300, return_eps=True)
+    X_t, e = ops.forward_noise(x, 2, T, eps=eps2, seed=seed, stream_id=stream_id, return_eps=True)
     xtj1 = ops.reverse_step(X_t, x, torch.zeros_like(x), x0_hat, 2, T, z=e * e, sched_host=DS.host)
     return disc(xtj1, X_t, 2)

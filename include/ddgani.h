@@ -70,7 +70,9 @@ int ddg_forward_noise(const float *x0, const float *eps, const int64_t *t, int t
  *       + (1-abar_{t-1}) b_t z/(1-abar_t)
  *   o = sqrt(abar_{t-1}) x + sqrt(1-abar_{t-1}) z ;   out = M o + (1-M) g
  * z: explicit noise or NULL -> on-chip Philox.  sched_host: HOST copy of ddg_schedule's out8.
- * In-place (out == x_t) is allowed.  Requires 3 <= t <= T.
+ * In-place (out == x_t) is allowed.  Requires 2 <= t <= T (t - 1 indexes abar_{t-1}): the sampler's
+ * reverse steps use t >= 3 (model/Diffusion.py:431-438); t = 2 is the posterior of the discriminator
+ * tail (:443-445), which ddgani_amd/model/Discriminator_model.py::sampler_disc_tail builds from this call.
  * ------------------------------------------------------------------------------------- */
 int ddg_reverse_step(const float *x_t, const float *x, const float *M, const float *pred,
                      const float *z, const float *sched_host, int T, int t,

@@ -48,6 +48,12 @@ import get_attr_attn as ref_attr                              # noqa: E402
 
 
 def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
+    # DDG_REF_THREADS=n DDG_SCORES_ONLY=1: run the reference with n intra-op threads and only print its scores as JSON
+    # (make_e2e_spread.py: how far the reference drifts from ITSELF when only the fp32 summation order changes)
+    threads = int(os.environ.get("DDG_REF_THREADS", "0"))
+    if threads:
+        torch.set_num_threads(threads)
+    scores_only = os.environ.get("DDG_SCORES_ONLY") == "1"
     params = json.load(open(R + "/param/param.json"))
     param = dict([p for p in params if p["name"] == name][0])
     param["epochs"] = epochs
@@ -87,6 +93,51 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
         return r
     ref_diff.get_valid_data_index = spy_v
 
+    # every sampling pass (model/Diffusion.py:594-635): the networks' weights, the state of torch's CPU generator right
+    # before the pass (its draws follow from it), the pass's outputs, the merged code and the decoded table.
+    # For the first pass the draws themselves are stored too (tests check that the replay from the state reproduces them).
+    passes = []
+    orig_s = ref_diff.reverse_diffusion_G_D_sample
+
+    def spy_s(generator_x, discriminator_noise_x, DS, timesteps, no, dim, device, x, M_tensor):
+        rec = {"rng_state": torch.get_rng_state().numpy().copy(),
+               "G": {k: v.detach().numpy().copy() for k, v in generator_x.state_dict().items()},
+               "Dn": {k: v.detach().numpy().copy() for k, v in discriminator_noise_x.state_dict().items()}}
+        if not passes:
+            st = torch.get_rng_state()
+            torch.randint(low=timesteps, high=timesteps + 1, size=(no,))
+            rec["eps_T"] = torch.randn(no, dim).numpy()
+            widths = (2 * dim, dim, 2 * dim)
+            for ts in range(timesteps, 1, -1):
+                if ts > 2:
+                    rec[f"z_t{ts}"] = torch.randn(no, dim).numpy()
+                for l, w_ in enumerate(widths):
+                    rec[f"drop_t{ts}_{l}"] = np.packbits(torch.empty(no, w_).bernoulli_(0.8).numpy().astype(np.uint8), axis=1)
+            rec["eps2"] = torch.randn(no, dim).numpy()
+            torch.set_rng_state(st)
+        r = orig_s(generator_x, discriminator_noise_x, DS, timesteps, no, dim, device, x, M_tensor)
+        rec["x0_hat"] = r[0].detach().numpy().copy()
+        rec["d_out"] = r[1].detach().numpy().copy()
+        rec["x"] = x.detach().numpy().copy()
+        passes.append(rec)
+        return r
+    ref_diff.reverse_diffusion_G_D_sample = spy_s
+
+    def spy2(code, fields, value_cat_, values_, miss_x, data_m_, enc_, ori_, con_):
+        miss_keep = miss_x.copy()            # reconvert_data ordinal-encodes its frame in place (utils/util.py:240)
+        r = orig(code, fields, value_cat_, values_, miss_x, data_m_, enc_, ori_, con_)
+        log.append((float(r[0]), float(r[1])))
+        rec = passes[-1]
+        rec["code"] = code.detach().numpy().copy()
+        dec = pd.DataFrame(ref_util.reconvert_data(code, fields, value_cat_, values_, miss_keep, data_m_, enc_))
+        dec.columns = values_
+        if value_cat_:
+            dec[value_cat_] = enc_.transform(dec[value_cat_])
+        rec["decoded"] = dec.values.astype(float)
+        rec["scores"] = np.array([float(r[0]), float(r[1])])
+        return r
+    ref_diff.test_impute_data_rmse = spy2
+
     np.random.seed(0); random.seed(0); torch.manual_seed(0)
     (ori_data, miss_data, data_m, label_data, true_data, true_label, continuous_cols, nan_data, test_data,
      all_data) = data_loader(label_file, miss_rate, param["categorical_cols"], "True", miss_type, seed)
@@ -102,6 +153,18 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
     fill_df = pd.DataFrame(fill, columns=values)
     armse, amae = ref_util.errorLoss(fill_df, ori_data, data_m, value_cat, continuous_cols, enc)
     print("reference:", name, "per-100-epoch scores", log, "final", armse, amae)
+    if scores_only:
+        dec = [p_["decoded"] for p_ in passes]
+        print("SCORES_JSON " + json.dumps({"threads": torch.get_num_threads(), "scores": log, "final": [armse, amae],
+                                           "decoded_sha": [__import__("hashlib").sha1(d.tobytes()).hexdigest() for d in dec],
+                                           "G_b4_ep10_sum": float(np.abs(snaps["G_b4_ep10"]).sum()),
+                                           "G_b4_ep100_sum": float(np.abs(snaps["G_b4_ep100"]).sum())}))
+        np.save(os.path.join(work, "dec.npy"), np.stack(dec))
+        shutil.copy(os.path.join(work, "dec.npy"), os.environ.get("DDG_DECODED_OUT", "/tmp/dec.npy"))
+        np.save(os.environ.get("DDG_DECODED_OUT", "/tmp/dec.npy") + ".w.npy",
+                np.concatenate([snaps[f"G_temb_ep{e}"].ravel() for e in (1, 2, 10, 100)]))
+        shutil.rmtree(work)
+        return
     attn = pd.read_csv(path + 'Attention_Input_miss_data_{}.csv'.format(miss_rate))
 
     def coded(df):
@@ -117,6 +180,15 @@ def main(name="hospital", epochs=200, miss_type="MCAR", miss_rate=0.2, seed=42):
                         categorical_cols=np.array(param["categorical_cols"], dtype=np.int64), T=np.array(param["T"]),
                         top_k=np.array(param["top_k"]), miss_rate=np.array(miss_rate), seed=np.array(seed),
                         param_json=np.array(json.dumps(param)), **snaps)
+    flat = {"n_passes": np.array(len(passes))}
+    for i, rec in enumerate(passes):
+        for k_, v in rec.items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    flat[f"p{i}__{k_}__" + kk.replace(".", "__")] = vv
+            else:
+                flat[f"p{i}__{k_}"] = v
+    np.savez_compressed(os.path.join(HERE, f"e2e_{tag}_passes.npz"), **flat)
     shutil.rmtree(work)
 
 
