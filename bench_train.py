@@ -18,10 +18,33 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--rows", type=int, default=200_000)
     ap.add_argument("--epochs", type=int, default=50)
+    ap.add_argument("--gpus", type=int, default=1, help="data-parallel ranks (sync-BatchNorm + gradient all-reduce)")
+    ap.add_argument("--backend", default="nccl", help="nccl = RCCL; gloo with --one-device rehearses on a one-GPU box")
+    ap.add_argument("--one-device", action="store_true")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:       # start the ranks as a child, before touching the GPU
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
     from ddgani_amd import ops, synth
+    from ddgani_amd import dist as ddist
     from ddgani_amd.model import Diffusion as D_, Discriminator_model as DM
-    dev = torch.device("cuda:0")
+    comm = ddist.Comm()
     tab = synth.make_table(a.workload, dev, rows=a.rows)
     lay, T = tab.layout, tab.T
 
@@ -40,9 +63,9 @@ def main():
 
     def epoch(e):
         D_.train_one_epoch_Generator(G, Dn, DS, tab.x_diff, optG, None, 0.0, e, a.epochs, T, dev, None, tab.M, m_data, lw,
-                                     [], None, None, rnd=rnd)
+                                     [], None, None, rnd=rnd, comm=comm)
         D_.train_one_epoch_discriminator_noise_x(G, Dn, DS, tab.x_diff, optD, None, 0.0, e, a.epochs, T, dev, None, tab.M,
-                                                 m_data, lw, rnd=rnd)
+                                                 m_data, lw, rnd=rnd, comm=comm)
     for e in range(1, 4):
         epoch(e)
     torch.cuda.synchronize()
@@ -52,10 +75,20 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = a.epochs * 2 * T
-    print(json.dumps({"metric": "training steps/s (generator + discriminator minibatch steps, B=128)",
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if comm.rank == 0:
+      print(json.dumps({"metric": "training steps/s (generator + discriminator minibatch steps, B=128)",
                       "value": steps / dt, "unit": "steps/s", "ms_per_step": dt / steps * 1e3,
                       "config": {"workload": a.workload, "rows": a.rows, "encoded_dim": lay.D, "cols": lay.C, "T": T,
-                                 "epochs": a.epochs, "rng": "chip"}, "dtype": "f32", "data": "synthetic"}))
+                                 "epochs": a.epochs, "rng": "chip",
+                                 "parallelism": f"data-parallel x{world} (B=128 sharded by rows, sync-BN, one gradient "
+                                                f"all-reduce per step, backend {a.backend})" if world > 1 else "single GPU"},
+                      "n_gpus": world, "dtype": "f32", "data": "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -47,6 +47,14 @@ class DiscGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "e1", "e2", "e3")]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # ddg_allreduce_fn
+
+
+class Dp(C.Structure):
+    """struct ddg_dp (include/ddgani.h)."""
+    _fields_ = [("global_rows", C.c_int64), ("allreduce", ALLREDUCE_FN), ("ctx", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/ddgani.h declares
 SIGNATURES = {
     "ddg_version": (C.c_int, []),
@@ -81,6 +89,14 @@ SIGNATURES = {
     "ddg_train_disc_grads": (C.c_int, [C.POINTER(GenWeights), C.POINTER(DiscWeights), C.POINTER(TrainBatch), c_f32p,
                                        C.c_int, c_i32p, c_u8p, C.c_int, C.c_float, C.c_float,
                                        C.POINTER(DiscGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_train_gen_grads_dp": (C.c_int, [C.POINTER(GenWeights), C.POINTER(DiscWeights), C.POINTER(TrainBatch), c_f32p,
+                                         C.c_int, c_i32p, c_u8p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.POINTER(GenGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                         C.POINTER(Dp)]),
+    "ddg_train_disc_grads_dp": (C.c_int, [C.POINTER(GenWeights), C.POINTER(DiscWeights), C.POINTER(TrainBatch), c_f32p,
+                                          C.c_int, c_i32p, c_u8p, C.c_int, C.c_float, C.c_float,
+                                          C.POINTER(DiscGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(Dp)]),
     "ddg_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_void_p]),

@@ -19,6 +19,7 @@ extern "C" const char *ddg_error_string(int code) {
         case DDG_E_UNSUPPORTED: return "unsupported shape";
         case DDG_E_WORKSPACE: return "workspace too small";
         case DDG_E_LAUNCH: return "kernel launch failed";
+        case DDG_E_COLLECTIVE: return "the caller's all-reduce callback failed";
         case DDG_E_SCRATCH_LIMIT: return "input exceeds the static scratch of this entry point (use the workspace variant)";
         default: return "unknown error";
     }

@@ -156,6 +156,61 @@ __global__ void k_bn_act_bwd(const float *__restrict__ dh, const float *__restri
     }
 }
 
+// The same backward split at its batch reduction (data-parallel step: the two column sums are all-reduced between
+// the kernels).  `rows` = local rows, `rows_g` = rows of the global batch (BatchNorm statistics are global).
+__global__ void k_bn_bwd_sums(const float *__restrict__ dh, const float *__restrict__ gate, const float *__restrict__ z,
+                              const double *__restrict__ stats, float eps, int rows, double rows_g, int width,
+                              float *__restrict__ sums, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= width) return;
+    const double mean_d = stats[k] / rows_g;
+    double var = stats[width + k] / rows_g - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = (float)mean_d;
+    float sda = 0.f, sdx = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const int64_t e = (int64_t)r * width + k;
+        const float da = dh[e] * gate[e];
+        sda += da;
+        sdx += da * ((z[e] - mean) * invstd);
+    }
+    dgamma[k] = sdx;          // this rank's share: the gradient all-reduce completes it
+    dbeta[k] = sda;
+    sums[k] = sda;
+    sums[width + k] = sdx;
+}
+__global__ void k_bn_bwd_apply(const float *__restrict__ dh, const float *__restrict__ gate, const float *__restrict__ z,
+                               const double *__restrict__ stats, const float *__restrict__ gamma, float eps, int rows,
+                               double rows_g, int width, const float *__restrict__ sums, float *__restrict__ dz) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * width) return;
+    const int k = e % width;
+    const double mean_d = stats[k] / rows_g;
+    double var = stats[width + k] / rows_g - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = (float)mean_d;
+    const float gi = gamma[k] * invstd, inv_n = 1.f / (float)rows_g;
+    const float da = dh[e] * gate[e];
+    const float xh = (z[e] - mean) * invstd;
+    dz[e] = gi * (da - sums[k] * inv_n - xh * sums[width + k] * inv_n);
+}
+
+// rows of the local batch whose mask block of field f is all ones (res_loss_func's per-field row count)
+__global__ void k_res_ngood(const float *__restrict__ M, const int32_t *__restrict__ offsets, int C, int rows, int D,
+                            float *__restrict__ ngood) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= C) return;
+    int n = 0;
+    for (int r = 0; r < rows; ++r) {
+        bool good = true;
+        for (int j = offsets[f]; j < offsets[f + 1]; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
+        n += good ? 1 : 0;
+    }
+    ngood[f] = (float)n;
+}
+
 // discriminator hidden activation r = relu(a + e[t]) and its backward
 __global__ void k_emb_relu_fwd(const float *__restrict__ a, const float *__restrict__ emb,
                                const int64_t *__restrict__ t, int rows, int width, float *__restrict__ r_out) {
@@ -196,7 +251,8 @@ __global__ void k_xtj1_train(const float *__restrict__ pred, const float *__rest
 __global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__restrict__ x0,
                                 const float *__restrict__ M, const int32_t *__restrict__ offsets,
                                 const uint8_t *__restrict__ is_cat, int C, int rows, int D,
-                                float *__restrict__ dpred, float *__restrict__ loss_out) {
+                                const float *__restrict__ ngood_global, float *__restrict__ dpred,
+                                float *__restrict__ loss_out) {
     extern __shared__ int sh_i[];
     int *ngood = sh_i;                       // [C]
     __shared__ double lsum[2];
@@ -210,11 +266,15 @@ __global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__r
         nfield[1] = nc > 0 ? nc : 1;
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
-        const int r = w / C, f = w - r * C;
-        bool good = true;
-        for (int j = offsets[f]; j < offsets[f + 1]; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
-        if (good) atomicAdd(&ngood[f], 1);
+    if (ngood_global) {          // data-parallel step: the counts of the GLOBAL batch (all-reduced by the caller)
+        for (int f = threadIdx.x; f < C; f += blockDim.x) ngood[f] = (int)ngood_global[f];
+    } else {
+        for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
+            const int r = w / C, f = w - r * C;
+            bool good = true;
+            for (int j = offsets[f]; j < offsets[f + 1]; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
+            if (good) atomicAdd(&ngood[f], 1);
+        }
     }
     __syncthreads();
     for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
@@ -251,8 +311,8 @@ __global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__r
 }
 
 // discriminator output, loss and d(loss)/d(logit).  mode 0: G_d_loss_func (:504); mode 1: D_loss_func (:523)
-__global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__restrict__ m, int n, int mode,
-                                 float scale, float *__restrict__ da4, float *__restrict__ loss_out) {
+__global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__restrict__ m, int n, int64_t n_norm,
+                                 int mode, float scale, float *__restrict__ da4, float *__restrict__ loss_out) {
     __shared__ double part[256];
     double l = 0.0;
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
@@ -266,7 +326,7 @@ __global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__re
             l += -(double)((1.f - mm) * logf(1.f - d + 1e-4f) + mm * logf(d + 1e-4f));
             dl = (1.f - mm) / (1.f - d + 1e-4f) - mm / (d + 1e-4f);
         }
-        da4[e] = scale * dl / (float)n * d * (1.f - d);
+        da4[e] = scale * dl / (float)n_norm * d * (1.f - d);
     }
     part[threadIdx.x] = l;
     __syncthreads();
@@ -274,7 +334,7 @@ __global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__re
         if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss_out[0] = (float)(part[0] / n);
+    if (threadIdx.x == 0) loss_out[0] = (float)(part[0] / (double)n_norm);
 }
 
 // total d(loss)/d(pred) = w_res * dres + dxtj1 * (1-M) * sqrt(abar_{t-1}) beta_t / (1-abar_t), then the
@@ -380,6 +440,7 @@ struct TrainWs {
     float *sc[3], *sf[3];
     float *xtj1, *a1, *r1, *a2, *r2, *a3, *r3, *a4, *da4, *dA, *dB, *dcat;
     float *dres, *dy, *dh, *dz;
+    float *bsum, *ngood;       // data-parallel step: BatchNorm backward column sums [2*max width], per-field row counts [C]
     float *fwd_ws;             // workspace of ddg_denoiser_fwd (discriminator step)
     size_t fwd_ws_bytes;
     size_t total;
@@ -401,6 +462,7 @@ static void train_carve(TrainWs &w, char *base, int64_t B, int D, int E, int L, 
     w.a1 = f(B * H); w.r1 = f(B * H); w.a2 = f(B * H); w.r2 = f(B * H); w.a3 = f(B * H); w.r3 = f(B * H);
     w.a4 = f(B * C); w.da4 = f(B * C); w.dA = f(B * H); w.dB = f(B * H); w.dcat = f(B * 2 * D);
     w.dres = f(B * D); w.dy = f(B * D); w.dh = f(B * mx); w.dz = f(B * mx);
+    w.bsum = f(2 * mx); w.ngood = f(C);
     w.fwd_ws_bytes = ddg_denoiser_workspace_bytes(B, D, E, L);
     w.fwd_ws = (float *)take(w.fwd_ws_bytes);
     w.total = o;
@@ -423,9 +485,27 @@ static int check_batch(const ddg_train_batch *b) {
 }
 
 // forward of the denoiser with every activation kept (model/Diffusion.py:179-201, train mode)
+// data-parallel context of one step: rows of the global batch and the caller's all-reduce (NULL: single process)
+struct Dp {
+    int64_t Bg;
+    ddg_allreduce_fn ar;
+    void *ctx;
+};
+static Dp dp_of(const ddg_dp *dp, int64_t local_rows) {
+    Dp d;
+    d.Bg = (dp && dp->allreduce) ? dp->global_rows : local_rows;
+    d.ar = dp ? dp->allreduce : nullptr;
+    d.ctx = dp ? dp->ctx : nullptr;
+    return d;
+}
+static int dp_allreduce(const Dp &dp, void *buf, int64_t count, int is_f64, void *stream) {
+    if (!dp.ar) return DDG_OK;
+    return dp.ar(dp.ctx, buf, count, is_f64, stream) == 0 ? DDG_OK : DDG_E_COLLECTIVE;
+}
+
 static int gen_forward_saved(const ddg_gen_weights *w, const ddg_train_batch *b, const float *sched, int T,
                              const int32_t *offsets, const uint8_t *is_cat, int C, float bn_eps, TrainWs &ws,
-                             void *stream) {
+                             void *stream, const Dp &dp) {
     hipStream_t s = (hipStream_t)stream;
     const int B = (int)b->rows, D = w->in_dim, E = w->enc_dim, L = w->lat_dim;
     int rc = ddg_forward_noise(b->x0, b->eps, b->t, 0, sched, T, b->seed, b->stream_id * 8 + 7, ws.xt,
@@ -444,7 +524,8 @@ static int gen_forward_saved(const ddg_gen_weights *w, const ddg_train_batch *b,
         rc = ddg_linear(hin, nullptr, win[l], Wl[l], bl[l], DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr,
                         nullptr, 0.f, 0, 0, zl[l], ws.st[l], B, win[l], wout[l], stream);
         if (rc) return rc;
-        rc = ddg_bn_finalize(ws.st[l], gl[l], bel[l], (double)B, bn_eps, ws.sc[l], ws.sf[l], wout[l], stream);
+        if ((rc = dp_allreduce(dp, ws.st[l], 2 * wout[l], 1, stream))) return rc;      // sync-BatchNorm: global sums
+        rc = ddg_bn_finalize(ws.st[l], gl[l], bel[l], (double)dp.Bg, bn_eps, ws.sc[l], ws.sf[l], wout[l], stream);
         if (rc) return rc;
         k_bn_act_fwd<<<g256((int64_t)B * wout[l]), 256, 0, s>>>(zl[l], ws.sc[l], ws.sf[l], dl[l], b->drop_p, b->seed,
                                                                b->stream_id * 4 + l, B, wout[l], hl[l], gt[l]);
@@ -487,13 +568,15 @@ static int disc_forward_saved(const ddg_disc_weights *dw, const ddg_train_batch 
 // ---------------------------------------------------------------------------------------------
 // generator step: loss = w_res * Res + w_gd * G_D, gradients of every generator parameter
 // ---------------------------------------------------------------------------------------------
-extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
-                                   const float *sched_dev, int T, const int32_t *offsets_dev,
-                                   const uint8_t *is_cat_dev, int C, float w_res, float w_gd, float bn_eps,
-                                   const ddg_gen_grads *grads, float *losses_dev, float *pred_out, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
+extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                                      const float *sched_dev, int T, const int32_t *offsets_dev,
+                                      const uint8_t *is_cat_dev, int C, float w_res, float w_gd, float bn_eps,
+                                      const ddg_gen_grads *grads, float *losses_dev, float *pred_out, void *workspace,
+                                      size_t workspace_bytes, void *stream, const ddg_dp *dpp) {
     int rc = check_batch(b);
     if (rc) return rc;
+    const Dp dp = dp_of(dpp, b->rows);
+    if (dp.Bg < b->rows) return DDG_E_ARG;
     if (!gw || !dw || !sched_dev || !offsets_dev || !is_cat_dev || !grads || !losses_dev || C < 1 || T < 2)
         return DDG_E_ARG;
     const int B = (int)b->rows, D = gw->in_dim, E = gw->enc_dim, L = gw->lat_dim, H = dw->lat_dim;
@@ -503,13 +586,13 @@ extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_wei
     if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
 
-    rc = gen_forward_saved(gw, b, sched_dev, T, offsets_dev, is_cat_dev, C, bn_eps, ws, stream);
+    rc = gen_forward_saved(gw, b, sched_dev, T, offsets_dev, is_cat_dev, C, bn_eps, ws, stream, dp);
     if (rc) return rc;
     const float *eps = b->eps ? b->eps : ws.dres;
     // G_D branch first (it reads the on-chip eps parked in ws.dres), then the reconstruction loss
     rc = disc_forward_saved(dw, b, ws.pred, eps, sched_dev, T, D, ws, stream);
     if (rc) return rc;
-    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, 0, w_gd, ws.da4, losses_dev + 1);
+    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 0, w_gd, ws.da4, losses_dev + 1);
     // input gradient of the discriminator: da4 -> r3 -> a3 -> r2 -> a2 -> r1 -> a1 -> cat(xtj1, x_t)
     if ((rc = gemm_dA(ws.da4, dw->W4, ws.dA, B, H, C, s))) return rc;
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
@@ -519,7 +602,13 @@ extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_wei
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r1, B * H, ws.dB);
     if ((rc = gemm_dA(ws.dB, dw->W1, ws.dcat, B, 2 * D, H, s))) return rc;
 
-    k_res_loss_grad<<<1, 256, (size_t)C * 4, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ws.dres,
+    const float *ngood = nullptr;
+    if (dp.ar) {                 // res_loss_func normalises per field by the row count of the GLOBAL batch
+        k_res_ngood<<<g256(C), 256, 0, s>>>(b->M, offsets_dev, C, B, D, ws.ngood);
+        if ((rc = dp_allreduce(dp, ws.ngood, C, 0, stream))) return rc;
+        ngood = ws.ngood;
+    }
+    k_res_loss_grad<<<1, 256, (size_t)C * 4, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ngood, ws.dres,
                                                   losses_dev);
     k_head_bwd<<<g256((int64_t)B * C), 256, 0, s>>>(ws.dres, w_res, ws.dcat, 2 * D, b->M, b->t, sched_dev, T, ws.pred,
                                                    offsets_dev, is_cat_dev, C, B, D, ws.dy);
@@ -535,8 +624,16 @@ extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_wei
     const float *hin[3] = {ws.h0, ws.h1, ws.h2};
     const int win[3] = {D, E, L}, wout[3] = {E, L, E};
     for (int l = 2; l >= 0; --l) {
-        k_bn_act_bwd<<<(wout[l] + 63) / 64, 64, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l], ws.dz,
-                                                        dgl[l], dbel[l]);
+        if (dp.ar) {
+            k_bn_bwd_sums<<<(wout[l] + 63) / 64, 64, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], bn_eps, B, (double)dp.Bg,
+                                                             wout[l], ws.bsum, dgl[l], dbel[l]);
+            if ((rc = dp_allreduce(dp, ws.bsum, 2 * wout[l], 0, stream))) return rc;
+            k_bn_bwd_apply<<<g256((int64_t)B * wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B,
+                                                                     (double)dp.Bg, wout[l], ws.bsum, ws.dz);
+        } else {
+            k_bn_act_bwd<<<(wout[l] + 63) / 64, 64, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l],
+                                                            ws.dz, dgl[l], dbel[l]);
+        }
         if ((rc = gemm_dW(ws.dz, hin[l], dWl[l], B, win[l], wout[l], s))) return rc;
         k_colsum<<<g256(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
         if ((rc = gemm_dA(ws.dz, Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
@@ -549,16 +646,27 @@ extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_wei
     return DDG_OK;
 }
 
+extern "C" int ddg_train_gen_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                                   const float *sched_dev, int T, const int32_t *offsets_dev,
+                                   const uint8_t *is_cat_dev, int C, float w_res, float w_gd, float bn_eps,
+                                   const ddg_gen_grads *grads, float *losses_dev, float *pred_out, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    return ddg_train_gen_grads_dp(gw, dw, b, sched_dev, T, offsets_dev, is_cat_dev, C, w_res, w_gd, bn_eps, grads,
+                                  losses_dev, pred_out, workspace, workspace_bytes, stream, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------
 // discriminator step: loss = loss_scale * D_loss, gradients of every discriminator parameter
 // ---------------------------------------------------------------------------------------------
-extern "C" int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
-                                    const float *sched_dev, int T, const int32_t *offsets_dev,
-                                    const uint8_t *is_cat_dev, int C, float loss_scale, float bn_eps,
-                                    const ddg_disc_grads *grads, float *loss_dev, float *pred_out, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
+extern "C" int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                                       const float *sched_dev, int T, const int32_t *offsets_dev,
+                                       const uint8_t *is_cat_dev, int C, float loss_scale, float bn_eps,
+                                       const ddg_disc_grads *grads, float *loss_dev, float *pred_out, void *workspace,
+                                       size_t workspace_bytes, void *stream, const ddg_dp *dpp) {
     int rc = check_batch(b);
     if (rc) return rc;
+    const Dp dp = dp_of(dpp, b->rows);
+    if (dp.Bg < b->rows) return DDG_E_ARG;
     if (!gw || !dw || !sched_dev || !offsets_dev || !is_cat_dev || !grads || !loss_dev || C < 1 || T < 2)
         return DDG_E_ARG;
     const int B = (int)b->rows, D = gw->in_dim, E = gw->enc_dim, L = gw->lat_dim, H = dw->lat_dim;
@@ -568,17 +676,23 @@ extern "C" int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_we
     if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
 
-    // generator forward only (fused inference path, train-mode BN + dropout)
-    rc = ddg_forward_noise(b->x0, b->eps, b->t, 0, sched_dev, T, b->seed, b->stream_id * 8 + 7, ws.xt,
-                           b->eps ? nullptr : ws.dres, B, D, stream);
-    if (rc) return rc;
-    rc = ddg_denoiser_fwd(gw, ws.xt, b->t, 0, b->drop0, b->drop1, b->drop2, b->drop_p, b->seed, b->stream_id, bn_eps,
-                          offsets_dev, is_cat_dev, C, 1, ws.pred, B, ws.fwd_ws, ws.fwd_ws_bytes, stream);
-    if (rc) return rc;
+    if (dp.ar) {
+        // data-parallel: the layer-by-layer forward, which has the sync-BatchNorm seams
+        rc = gen_forward_saved(gw, b, sched_dev, T, offsets_dev, is_cat_dev, C, bn_eps, ws, stream, dp);
+        if (rc) return rc;
+    } else {
+        // generator forward only (fused inference path, train-mode BN + dropout)
+        rc = ddg_forward_noise(b->x0, b->eps, b->t, 0, sched_dev, T, b->seed, b->stream_id * 8 + 7, ws.xt,
+                               b->eps ? nullptr : ws.dres, B, D, stream);
+        if (rc) return rc;
+        rc = ddg_denoiser_fwd(gw, ws.xt, b->t, 0, b->drop0, b->drop1, b->drop2, b->drop_p, b->seed, b->stream_id,
+                              bn_eps, offsets_dev, is_cat_dev, C, 1, ws.pred, B, ws.fwd_ws, ws.fwd_ws_bytes, stream);
+        if (rc) return rc;
+    }
     const float *eps = b->eps ? b->eps : ws.dres;
     rc = disc_forward_saved(dw, b, ws.pred, eps, sched_dev, T, D, ws, stream);
     if (rc) return rc;
-    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, 1, loss_scale, ws.da4, loss_dev);
+    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 1, loss_scale, ws.da4, loss_dev);
     // layer 4
     if ((rc = gemm_dW(ws.da4, ws.r3, grads->W4, B, H, C, s))) return rc;
     k_colsum<<<g256(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
@@ -606,4 +720,13 @@ extern "C" int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_we
         return DDG_E_LAUNCH;
     DDG_CHECK_LAUNCH();
     return DDG_OK;
+}
+
+extern "C" int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                                    const float *sched_dev, int T, const int32_t *offsets_dev,
+                                    const uint8_t *is_cat_dev, int C, float loss_scale, float bn_eps,
+                                    const ddg_disc_grads *grads, float *loss_dev, float *pred_out, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return ddg_train_disc_grads_dp(gw, dw, b, sched_dev, T, offsets_dev, is_cat_dev, C, loss_scale, bn_eps, grads,
+                                   loss_dev, pred_out, workspace, workspace_bytes, stream, nullptr);
 }

@@ -124,3 +124,42 @@ def sharded_reverse_sample(comm: Comm, backend, P, T: int, x, M, layout, N_total
                                        stream_id=stream_of(call, KIND_Z, ts, rk), out=x_t)
         i += 1
     return pred
+
+
+def batch_bounds(batch: int, world: int):
+    """rows of the global minibatch owned by each rank (contiguous, sizes differ by at most one, never empty for
+    batch >= world)"""
+    base, rem = divmod(batch, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def sharded_train_step(comm: Comm, backend, which: str, PG, PD, state, x0, M, m, t, layout, sched_dev, T: int,
+                       loss_weight=None, loss_scale: float = 1.0, eps=None, drops=None, seed: int = 0,
+                       stream_id: int = 0):
+    """One data-parallel minibatch step (model/Diffusion.py:287-311 generator, :356-372 discriminator): every rank
+    holds the same GLOBAL batch (x0, M, m, t and, in parity mode, eps / drops: the same indices and draws on every
+    rank), computes the gradients of its row share with synchronised BatchNorm (ddg_train_*_grads_dp all-reduces the
+    BatchNorm sums through ``comm``), all-reduces the flat gradient buffer once (RCCL: ``nccl`` backend) and takes the
+    identical Adam step.  ``state``: model.Diffusion._NetState of the network being trained.
+    -> loss values of the global batch (device tensor: [res, g_d] or [d_loss])."""
+    B = x0.shape[0]
+    lo, hi = batch_bounds(B, comm.world)[comm.rank]
+    cut = lambda a: None if a is None else a[lo:hi].contiguous()
+    dp = backend.DataParallel(B, comm.all_reduce_sum) if comm.on else None
+    kw = dict(eps=cut(eps), drops=None if drops is None else [cut(d) for d in drops], seed=seed, stream_id=stream_id,
+              dp=dp)
+    if which == "G":
+        losses, _ = backend.train_gen_grads(PG, PD, state.buf, cut(x0), cut(M), cut(m), cut(t), layout, sched_dev, T,
+                                            loss_weight["Res_weight"], loss_weight["G_D_weight"], **kw)
+    else:
+        losses, _ = backend.train_disc_grads(PG, PD, state.buf, cut(x0), cut(M), cut(m), cut(t), layout, sched_dev, T,
+                                             loss_scale=loss_scale, **kw)
+    if comm.on:
+        comm.all_reduce_sum(state.buf.flat)          # gradients + loss values in one collective
+    state.step()
+    return losses.clone()

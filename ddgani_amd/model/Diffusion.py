@@ -274,7 +274,7 @@ class _NetState:
         self.buf.adam_step(lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=self.wd)
 
 
-def _train_batch(rnd, x, M, m_data, T, device, gen_widths):
+def _train_batch(rnd, x, M, m_data, T, device, gen_widths, rank: int = 0):
     idx = rnd.batch_indices(x.shape[0], 128)                  # batch hard-coded to 128 (model/Diffusion.py:287)
     it = torch.as_tensor(idx, dtype=torch.long, device=device)
     x0, Mb, mb = x[it].contiguous(), M[it].contiguous(), m_data[it].contiguous()
@@ -284,26 +284,34 @@ def _train_batch(rnd, x, M, m_data, T, device, gen_widths):
         drops = rnd.dropout(x0.shape[0], gen_widths, device)
         return x0, Mb, mb, t, dict(eps=eps, drops=drops)
     # one stream number for the step: the library derives eps (normal) and the three dropout layers from it
-    return x0, Mb, mb, t, dict(seed=rnd.seed, stream_id=stream_of(rnd.next_stream(), KIND_EPS))
+    return x0, Mb, mb, t, dict(seed=rnd.seed, stream_id=stream_of(rnd.next_stream(), KIND_EPS, rank=rank))
 
 
 def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, loss_scaler, other_loss, epoch,
                               total_epochs, timesteps, device, field, M, m_data, loss_weight, FDs_model_list, fields,
-                              zero_feed_data, rnd=None):
+                              zero_feed_data, rnd=None, comm=None):
     """reference: model/Diffusion.py:245-318.  ``timesteps`` minibatch steps of the generator:
     loss = Res*Res_weight + G_D*G_D_weight (+ the FD / Learner terms, constants under no_grad that do
     not reach a gradient).  ``optimizer`` is the generator's ``_NetState``; ``loss_scaler`` is unused
-    (the reference's generator step does not use it either, :306-311).  Returns the mean loss."""
+    (the reference's generator step does not use it either, :306-311).  Returns the mean loss.
+    ``comm`` (ddgani_amd.dist.Comm of a multi-rank job): every rank draws the same 128 rows and timesteps, the
+    step runs data-parallel over their rows (sync-BatchNorm + one gradient all-reduce over RCCL)."""
     rnd = rnd or HostRandom()
     PG, PD = optimizer.P, discriminator_noise_x.device_params()
     widths = (PG.enc_dim, PG.lat_dim, PG.enc_dim)
     total = 0.0
     losses = []
+    dp = comm is not None and comm.on
     for _ in range(timesteps):
-        x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths)
-        l, _ = ops.train_gen_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, model.layout, DS.table, timesteps,
-                                   loss_weight["Res_weight"], loss_weight["G_D_weight"], **kw)
-        optimizer.step()
+        x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths, rank=comm.rank if dp else 0)
+        if dp:
+            from .. import dist as ddist
+            l = ddist.sharded_train_step(comm, ops, "G", PG, PD, optimizer, x0, Mb, mb, t, model.layout, DS.table,
+                                         timesteps, loss_weight=loss_weight, **kw)
+        else:
+            l, _ = ops.train_gen_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, model.layout, DS.table, timesteps,
+                                       loss_weight["Res_weight"], loss_weight["G_D_weight"], **kw)
+            optimizer.step()
         losses.append(l)
     if losses:
         ls = torch.stack(losses).double().cpu()
@@ -314,19 +322,25 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
 
 def train_one_epoch_discriminator_noise_x(generator_x0, discriminator_noise_x, DS, x, optimizer, loss_scaler,
                                           other_loss, epoch, total_epochs, timesteps, device, field, M, m_data,
-                                          loss_weight, rnd=None):
+                                          loss_weight, rnd=None, comm=None):
     """reference: model/Diffusion.py:321-379.  ``timesteps`` minibatch steps of the discriminator on
-    D_loss_func (scaled by D_weight on epochs divisible by 100, :338 vs :367)."""
+    D_loss_func (scaled by D_weight on epochs divisible by 100, :338 vs :367).  ``comm``: as above."""
     rnd = rnd or HostRandom()
     PG, PD = generator_x0.device_params(), optimizer.P
     widths = (PG.enc_dim, PG.lat_dim, PG.enc_dim)
     scale = loss_weight["D_weight"] if epoch % 100 == 0 else 1.0
     losses = []
+    dp = comm is not None and comm.on
     for _ in range(timesteps):
-        x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths)
-        l, _ = ops.train_disc_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, generator_x0.layout, DS.table, timesteps,
-                                    loss_scale=scale, **kw)
-        optimizer.step()
+        x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths, rank=comm.rank if dp else 0)
+        if dp:
+            from .. import dist as ddist
+            l = ddist.sharded_train_step(comm, ops, "D", PG, PD, optimizer, x0, Mb, mb, t, generator_x0.layout,
+                                         DS.table, timesteps, loss_scale=scale, **kw)
+        else:
+            l, _ = ops.train_disc_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, generator_x0.layout, DS.table,
+                                        timesteps, loss_scale=scale, **kw)
+            optimizer.step()
         losses.append(l)
     return float(torch.stack(losses).double().mean().cpu()) * scale if losses else 0.0
 

@@ -285,12 +285,21 @@ def _batch_struct(x0, M, m, t, eps, drops, drop_p, seed, stream_id) -> TrainBatc
 
 
 class ParamGrads:
-    """Gradient (and Adam moment) buffers shaped like a GenParams / DiscParams tensor dict."""
+    """Gradient (and Adam moment) buffers shaped like a GenParams / DiscParams tensor dict.  The gradients are views
+    of ONE flat buffer followed by ``n_extra`` floats (the step's loss values), so a data-parallel step completes them
+    with a single all-reduce (``flat``)."""
 
-    def __init__(self, P, keys):
+    def __init__(self, P, keys, n_extra: int = 2):
         self.keys = keys
         self.P = P
-        self.g = {k: torch.zeros_like(P.t[k]) for k in keys}
+        sizes = [P.t[k].numel() for k in keys]
+        dev = P.t[keys[0]].device
+        self.flat = torch.zeros(sum(sizes) + n_extra, dtype=torch.float32, device=dev)
+        self.g, o = {}, 0
+        for k, n in zip(keys, sizes):
+            self.g[k] = self.flat[o:o + n].view_as(P.t[k])
+            o += n
+        self.extra = self.flat[o:]
         self.exp_avg = {k: torch.zeros_like(P.t[k]) for k in keys}
         self.exp_avg_sq = {k: torch.zeros_like(P.t[k]) for k in keys}
         self.step = 0
@@ -306,6 +315,37 @@ class ParamGrads:
                                   betas[0], betas[1], eps, weight_decay, _stream()), "ddg_adam_step")
 
 
+class DataParallel:
+    """struct ddg_dp for one training-step call: ``allreduce(tensor)`` sums a device tensor in place over the ranks
+    (ddgani_amd.dist.Comm.all_reduce_sum).  The library names the buffers by device pointer; they lie inside the
+    step's workspace tensor, so the callback hands torch a typed view of that tensor."""
+
+    def __init__(self, global_rows: int, allreduce):
+        self.global_rows = int(global_rows)
+        self.allreduce = allreduce
+        self.ws = None
+        self.error = None
+
+        def cb(ctx, buf, count, is_f64, stream):
+            try:
+                off = int(buf) - self.ws.data_ptr()
+                nb = int(count) * (8 if is_f64 else 4)
+                if off < 0 or off + nb > self.ws.numel():
+                    raise _lib.DdgError("all-reduce buffer outside the step workspace")
+                self.allreduce(self.ws[off:off + nb].view(torch.float64 if is_f64 else torch.float32))
+                return 0
+            except Exception as e:          # never unwind through the C frame
+                self.error = e
+                return 1
+        self._cb = _lib.ALLREDUCE_FN(cb)
+        self.c = _lib.Dp(self.global_rows, self._cb, None)
+
+    def bind(self, ws):
+        self.ws = ws
+        self.error = None
+        return C.byref(self.c)
+
+
 def _train_ws(PG, PD, rows, C_, device):
     nb = lib().ddg_train_workspace_bytes(rows, PG.in_dim, PG.enc_dim, PG.lat_dim, PD.lat_dim, C_)
     return _workspace(nb, device, "train")
@@ -313,38 +353,48 @@ def _train_ws(PG, PD, rows, C_, device):
 
 def train_gen_grads(PG: "GenParams", PD: "DiscParams", grads: ParamGrads, x0, M, m, t, layout: FieldLayout,
                     sched_dev, T: int, w_res: float, w_gd: float, eps=None, drops=None, drop_p: float = 0.2,
-                    seed: int = 0, stream_id: int = 0, bn_eps: float = 1e-5, want_pred: bool = False):
+                    seed: int = 0, stream_id: int = 0, bn_eps: float = 1e-5, want_pred: bool = False,
+                    dp: Optional[DataParallel] = None):
     """Generator step up to the gradients (train_one_epoch_Generator, model/Diffusion.py:287-310).
-    Returns (losses[2] device tensor = res, g_d; pred or None)."""
+    Returns (losses[2] device tensor = res, g_d; pred or None).  With ``dp`` the rows are this rank's share of the
+    global batch and gradients / losses are this rank's share of the global ones (ddg_train_gen_grads_dp);
+    the losses land in ``grads.extra`` so that one all-reduce of ``grads.flat`` completes everything."""
     dev = x0.device
     off, cat = layout.on(dev)
     ws = _train_ws(PG, PD, x0.shape[0], layout.C, dev)
-    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    losses = grads.extra[:2] if dp is not None else torch.empty(2, dtype=torch.float32, device=dev)
     pred = torch.empty_like(x0) if want_pred else None
     b = _batch_struct(x0, M, m, t, eps, drops, drop_p, seed, stream_id)
     gs = GenGrads(*[grads.g[k].data_ptr() for k in GEN_KEYS])
-    check(lib().ddg_train_gen_grads(C.byref(PG.c), C.byref(PD.c), C.byref(b), _ptr(sched_dev, torch.float32), T,
-                                    _ptr(off), _ptr(cat), layout.C, float(w_res), float(w_gd), bn_eps, C.byref(gs),
-                                    _ptr(losses), _ptr(pred), ws.data_ptr(), ws.numel(), _stream()),
-          "ddg_train_gen_grads")
+    rc = lib().ddg_train_gen_grads_dp(C.byref(PG.c), C.byref(PD.c), C.byref(b), _ptr(sched_dev, torch.float32), T,
+                                      _ptr(off), _ptr(cat), layout.C, float(w_res), float(w_gd), bn_eps, C.byref(gs),
+                                      _ptr(losses), _ptr(pred), ws.data_ptr(), ws.numel(), _stream(),
+                                      dp.bind(ws) if dp is not None else None)
+    if dp is not None and dp.error is not None:
+        raise dp.error
+    check(rc, "ddg_train_gen_grads")
     return losses, pred
 
 
 def train_disc_grads(PG: "GenParams", PD: "DiscParams", grads: ParamGrads, x0, M, m, t, layout: FieldLayout,
                      sched_dev, T: int, loss_scale: float = 1.0, eps=None, drops=None, drop_p: float = 0.2,
-                     seed: int = 0, stream_id: int = 0, bn_eps: float = 1e-5, want_pred: bool = False):
+                     seed: int = 0, stream_id: int = 0, bn_eps: float = 1e-5, want_pred: bool = False,
+                     dp: Optional[DataParallel] = None):
     """Discriminator step up to the gradients (train_one_epoch_discriminator_noise_x, :356-370)."""
     dev = x0.device
     off, cat = layout.on(dev)
     ws = _train_ws(PG, PD, x0.shape[0], layout.C, dev)
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    loss = grads.extra[:1] if dp is not None else torch.empty(1, dtype=torch.float32, device=dev)
     pred = torch.empty_like(x0) if want_pred else None
     b = _batch_struct(x0, M, m, t, eps, drops, drop_p, seed, stream_id)
     gs = DiscGrads(*[grads.g[k].data_ptr() for k in DISC_KEYS])
-    check(lib().ddg_train_disc_grads(C.byref(PG.c), C.byref(PD.c), C.byref(b), _ptr(sched_dev, torch.float32), T,
-                                     _ptr(off), _ptr(cat), layout.C, float(loss_scale), bn_eps, C.byref(gs),
-                                     _ptr(loss), _ptr(pred), ws.data_ptr(), ws.numel(), _stream()),
-          "ddg_train_disc_grads")
+    rc = lib().ddg_train_disc_grads_dp(C.byref(PG.c), C.byref(PD.c), C.byref(b), _ptr(sched_dev, torch.float32), T,
+                                       _ptr(off), _ptr(cat), layout.C, float(loss_scale), bn_eps, C.byref(gs),
+                                       _ptr(loss), _ptr(pred), ws.data_ptr(), ws.numel(), _stream(),
+                                       dp.bind(ws) if dp is not None else None)
+    if dp is not None and dp.error is not None:
+        raise dp.error
+    check(rc, "ddg_train_disc_grads")
     return loss, pred
 
 

@@ -35,6 +35,7 @@ extern "C" {
 #define DDG_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for               */
 #define DDG_E_WORKSPACE (-3)  /* workspace too small                                        */
 #define DDG_E_LAUNCH (-4)     /* hipGetLastError() != hipSuccess after a launch             */
+#define DDG_E_COLLECTIVE (-6) /* the caller's all-reduce callback reported a failure            */
 #define DDG_E_SCRATCH_LIMIT (-5) /* input larger than the static scratch of a *_static entry point */
 
 #define DDG_MAX_D 256         /* widest encoded table the attention kernels are built for   */
@@ -239,6 +240,43 @@ int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_weights *dw, 
                          const float *sched_dev, int T, const int32_t *offsets_dev, const uint8_t *is_cat_dev,
                          int C, float loss_scale, float bn_eps, const ddg_disc_grads *grads, float *loss_dev,
                          float *pred_out, void *workspace, size_t workspace_bytes, void *stream);
+/* ---------------------------------------------------------------------------------------
+ * (e) data-parallel training step: the B = 128 minibatch of model/Diffusion.py:287-311 / :356-372
+ * sharded by rows over the ranks of one job (one process per GPU), with synchronised BatchNorm.
+ * No counterpart in the reference (single device); results equal the single-process step on the same
+ * global batch up to fp32 summation order.
+ *
+ * Each rank calls the *_dp entry point on ITS rows of the global batch (ddg_train_batch.rows = local
+ * rows >= 1; eps / drop masks / t are the rank's rows of the global draws).  The library has no RCCL
+ * inside: wherever the step reduces over the batch it calls `allreduce` (sum, in place, `count`
+ * elements of fp32 (is_f64 = 0) or fp64 (is_f64 = 1) at the DEVICE pointer `buf`, ordered on `stream`;
+ * return 0 on success):
+ *   forward   3 x BatchNorm column sums (sum z, sum z^2), fp64 [2*width]
+ *   losses    res_loss_func's per-field row counts, fp32 [C]            (generator step only)
+ *   backward  3 x BatchNorm backward column sums (sum da, sum da*xhat), fp32 [2*width]   (generator step only)
+ * `buf` always lies inside the workspace passed to the call.  Outputs are this rank's SHARE: gradients
+ * and losses are partial sums already normalised by the global counts, so the caller's one all-reduce
+ * (sum) over the gradient tensors and the loss floats completes them (ddgani_amd/dist.py:
+ * sharded_train_step keeps them in one flat buffer).  dp == NULL or dp->allreduce == NULL: the
+ * single-process step (ddg_train_gen_grads / ddg_train_disc_grads).
+ * ------------------------------------------------------------------------------------- */
+typedef int (*ddg_allreduce_fn)(void *ctx, void *buf, int64_t count, int is_f64, void *stream);
+typedef struct ddg_dp {
+    int64_t global_rows;        /* rows of the whole minibatch (128 in the reference) */
+    ddg_allreduce_fn allreduce;
+    void *ctx;
+} ddg_dp;
+int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                           const float *sched_dev, int T, const int32_t *offsets_dev, const uint8_t *is_cat_dev,
+                           int C, float w_res, float w_gd, float bn_eps, const ddg_gen_grads *grads,
+                           float *losses_dev, float *pred_out, void *workspace, size_t workspace_bytes,
+                           void *stream, const ddg_dp *dp);
+int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc_weights *dw, const ddg_train_batch *b,
+                            const float *sched_dev, int T, const int32_t *offsets_dev, const uint8_t *is_cat_dev,
+                            int C, float loss_scale, float bn_eps, const ddg_disc_grads *grads, float *loss_dev,
+                            float *pred_out, void *workspace, size_t workspace_bytes, void *stream,
+                            const ddg_dp *dp);
+
 /* host arrays of n_tensors (<= 16) device pointers; step counts from 1 */
 int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                   float *const *exp_avg_sq, const int64_t *numel, int step, double lr, double beta1,
