@@ -22,7 +22,7 @@ def get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, categor
     Mutates ``nan_data`` in place (mean / mode pre-fill) and round-trips the attention-filled table
     through ``Attention_Input_miss_data_<rate>.csv`` like the reference (:23-24)."""
     pathMiss = path + 'miss_data_{}.csv'.format(miss_rate)
-    corr_map = get_attr_map_Null_kendall(pathMiss, data_m, categorical_cols, continuous_cols)
+    corr_map = get_attr_map_Null_kendall(pathMiss, data_m, categorical_cols, continuous_cols, device=device)
     sort_corr_dict = sort_corr(corr_map)
     attention_data = Mean.fill_data_mean(nan_data, continuous_cols)
     attention_impute_data = pd.DataFrame(attention_data, columns=values)
@@ -38,10 +38,15 @@ def get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, categor
     fields, feed_data = Data_convert(cat_to_code_data, param['model_name'], continuous_cols)
     impute_data_code = torch.tensor(feed_data.values, dtype=torch.float).to(device)
     if args.UseFD == "True":
-        # the FD plug-in adds a constant (no_grad) to the generator loss: numerically inert for the
-        # imputation; its discovery / classifier training is a "next" row (8(f))
-        pass
-    FD_model_list = []
+        # reference :30-39: dependencies are discovered on the table with missing cells, the classifiers are trained
+        # on the observed part of the encoded table (M * code).  Their loss is a no_grad constant in the generator
+        # loss: numerically inert for the imputation, but it is what the flag computes.
+        from ..model.FD_model import get_FD_model_Tree
+        M_tensor = get_M_by_data_m(data_m, fields, device)
+        FD_model_list = get_FD_model_Tree(miss_data, data_m, categorical_cols, impute_data_code * M_tensor, fields,
+                                          device, sort_corr_dict)
+    else:
+        FD_model_list = []
     input_dim = feed_data.shape[1]
     latent_dim = input_dim // 2
     random.choice([500, 400, 300, 200, 100])              # the reference draws an unused width here (:45)

@@ -47,6 +47,11 @@ class DiscGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3", "W4", "b4", "e1", "e2", "e3")]
 
 
+class FdWeights(C.Structure):
+    """struct ddg_fd_weights (include/ddgani.h)."""
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W3", "b3")]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # ddg_allreduce_fn
 
 
@@ -111,6 +116,15 @@ SIGNATURES = {
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddg_attn_fill": (C.c_int, [C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int,
                                 C.c_int, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_fd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "ddg_fd_train_epoch": (C.c_int, [C.POINTER(FdWeights), c_f32p, c_i32p, c_i64p, C.c_int64, C.c_int, C.c_float,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_fd_eval": (C.c_int, [C.POINTER(FdWeights), c_f32p, c_i32p, C.c_int64, c_i32p, c_f32p, C.c_void_p, C.c_size_t,
+                              C.c_int64, C.c_void_p]),
+    "ddg_contingency": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p, c_i64p, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p]),
+    "ddg_score_table": (C.c_int, [c_f32p, c_f64p, c_u8p, c_i32p, c_u8p, c_f64p, c_f64p, c_u8p, c_f64p, c_f64p, c_f64p, c_f64p,
+                                  C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ddg_learner_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ddg_learner_train": (C.c_int, [c_f32p, c_i32p, C.c_int64, c_f32p, c_i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_float, c_f32p, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),

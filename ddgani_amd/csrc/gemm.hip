@@ -14,6 +14,7 @@
 // up to fp32 summation order.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -64,6 +65,105 @@ __device__ __forceinline__ float lin_transform(const LinArgs &p, float a, int64_
     return a;
 }
 
+// one float4 of the transformed A operand: rows `row`, columns k0..k0+3 (zeros outside the matrix)
+template <int PRO>
+__device__ __forceinline__ f32x4 lin_stage_a(const LinArgs &p, int64_t row, int k0, int trow, float keep_scale, bool fast) {
+    f32x4 av = {0.f, 0.f, 0.f, 0.f};
+    if (row >= p.rows) return av;
+    if (fast) {
+        // no concatenation and in % 4 == 0 -> one 16-byte load, the dropout mask one 4-byte load, one Philox call
+        if (k0 >= p.in) return av;
+        av = *reinterpret_cast<const f32x4 *>(p.A + row * p.in + k0);
+        if (PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) {
+            const f32x4 ev = *reinterpret_cast<const f32x4 *>(p.emb + (int64_t)trow * p.in + k0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                av[e] += ev[e];
+                if (PRO == DDG_PRO_EMB_RELU) av[e] = fmaxf(av[e], 0.f);
+            }
+        } else if (PRO == DDG_PRO_BN_RELU) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + k0);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.shift + k0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = fmaxf(av[e] * sc[e] + sh[e], 0.f);
+            if (p.drop) {
+                const uint32_t mk = *reinterpret_cast<const uint32_t *>(p.drop + row * p.in + k0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = ((mk >> (8 * e)) & 0xffu) ? av[e] * keep_scale : 0.f;
+            } else if (p.drop_p > 0.f) {
+                const uint64_t e0 = (uint64_t)row * (uint64_t)p.in + (uint64_t)k0;
+                const f32x4 u = philox_uniform4(p.seed, p.stream_id, e0 >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = (u[e] > p.drop_p) ? av[e] * keep_scale : 0.f;
+            }
+        }
+        return av;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = k0 + e;
+        if (k < p.in) av[e] = lin_transform<PRO>(p, lin_fetch_a(p, row, k), row, k, trow, keep_scale);
+    }
+    return av;
+}
+
+// one float4 of W: output column n, inputs k0..k0+3
+__device__ __forceinline__ f32x4 lin_stage_b(const LinArgs &p, int n, int k0, bool fast) {
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (n >= p.out) return bv;
+    if (fast) {
+        if (k0 < p.in) bv = *reinterpret_cast<const f32x4 *>(p.W + (int64_t)n * p.in + k0);
+        return bv;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = k0 + e;
+        if (k < p.in) bv[e] = p.W[(int64_t)n * p.in + k];
+    }
+    return bv;
+}
+
+// epilogue shared by both kernels: + bias, store, fp64 column statistics
+#define LIN_EPILOGUE(VAL)                                                                                       \
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                          \
+        const int col = col0 + wc * 64 + ct * 32 + r32;                                                         \
+        const bool cok = col < p.out;                                                                           \
+        const float bj = cok ? p.bias[col] : 0.f;                                                               \
+        _Pragma("unroll") for (int rt = 0; rt < 2; ++rt) {                                                      \
+            _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                    \
+                const int64_t row = row0 + wr * 64 + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;                  \
+                if (cok && row < p.rows) {                                                                      \
+                    const float v = (VAL) + bj;                                                                 \
+                    p.Y[row * p.out + col] = v;                                                                 \
+                    s1[ct] += (double)v;                                                                        \
+                    s2[ct] += (double)v * (double)v;                                                            \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
+#define LIN_STATS()                                                                                             \
+    if (p.stats) {                                                                                              \
+        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                      \
+            double a = s1[ct], b = s2[ct];                                                                      \
+            a += __shfl_xor(a, 32);                                                                             \
+            b += __shfl_xor(b, 32);                                                                             \
+            if (h == 0) { red[wid][ct][0][r32] = a; red[wid][ct][1][r32] = b; }                                 \
+        }                                                                                                       \
+        __syncthreads();                                                                                        \
+        if (wr == 0 && h == 0) {                                                                                \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                  \
+                const int col = col0 + wc * 64 + ct * 32 + r32;                                                 \
+                if (col < p.out) {                                                                              \
+                    const double a = red[wid][ct][0][r32] + red[wid + 2][ct][0][r32];                           \
+                    const double b = red[wid][ct][1][r32] + red[wid + 2][ct][1][r32];                           \
+                    atomicAdd(&p.stats[col], a);                                                                \
+                    atomicAdd(&p.stats[p.out + col], b);                                                        \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
 template <int PRO>
 __global__ __launch_bounds__(256, 2) void k_linear(LinArgs p) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_STRIDE];
@@ -78,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs p) {
     const int nchunks = (p.in + BK - 1) / BK;
     const int64_t ntiles = ceil_div64(p.rows, BM);
     const float keep_scale = 1.f / (1.f - p.drop_p);
+    const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
 
     double s1[2] = {0, 0}, s2[2] = {0, 0};
 
@@ -104,76 +205,14 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs p) {
                 trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
         }
 
-        // fast path: no concatenation and in % 4 == 0 -> every operand fragment is one 16-byte load, the
-        // dropout mask one 4-byte load, and one Philox call serves four elements
-        const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
         auto stage = [&](int buf, int chunk) {
             const int k0 = chunk * BK + st_c4 * 4;
-            if (fast) {
-                const bool kok = k0 < p.in;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int rl = st_r + 32 * i;
-                    const int64_t row = row0 + rl;
-                    f32x4 av = {0.f, 0.f, 0.f, 0.f};
-                    if (kok && row < p.rows) {
-                        av = *reinterpret_cast<const f32x4 *>(p.A + row * p.in + k0);
-                        if (PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) {
-                            const f32x4 ev = *reinterpret_cast<const f32x4 *>(p.emb + (int64_t)trows[i] * p.in + k0);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                av[e] += ev[e];
-                                if (PRO == DDG_PRO_EMB_RELU) av[e] = fmaxf(av[e], 0.f);
-                            }
-                        } else if (PRO == DDG_PRO_BN_RELU) {
-                            const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + k0);
-                            const f32x4 sh = *reinterpret_cast<const f32x4 *>(p.shift + k0);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) av[e] = fmaxf(av[e] * sc[e] + sh[e], 0.f);
-                            if (p.drop) {
-                                const uint32_t mk = *reinterpret_cast<const uint32_t *>(p.drop + row * p.in + k0);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) av[e] = ((mk >> (8 * e)) & 0xffu) ? av[e] * keep_scale : 0.f;
-                            } else if (p.drop_p > 0.f) {
-                                const uint64_t e0 = (uint64_t)row * (uint64_t)p.in + (uint64_t)k0;
-                                const f32x4 u = philox_uniform4(p.seed, p.stream_id, e0 >> 2);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) av[e] = (u[e] > p.drop_p) ? av[e] * keep_scale : 0.f;
-                            }
-                        }
-                    }
-                    *reinterpret_cast<f32x4 *>(&As[buf][rl * LDS_STRIDE + st_c4 * 4]) = av;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    const int n = col0 + rl;
-                    if (kok && n < p.out) bv = *reinterpret_cast<const f32x4 *>(p.W + (int64_t)n * p.in + k0);
-                    *reinterpret_cast<f32x4 *>(&Bs[buf][rl * LDS_STRIDE + st_c4 * 4]) = bv;
-                }
-                return;
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rl = st_r + 32 * i;
-                const int64_t row = row0 + rl;
-                f32x4 av = {0.f, 0.f, 0.f, 0.f};
-                if (row < p.rows) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = k0 + e;
-                        if (k < p.in)
-                            av[e] = lin_transform<PRO>(p, lin_fetch_a(p, row, k), row, k, trows[i], keep_scale);
-                    }
-                }
-                *reinterpret_cast<f32x4 *>(&As[buf][rl * LDS_STRIDE + st_c4 * 4]) = av;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                const int n = col0 + rl;
-                if (n < p.out) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = k0 + e;
-                        if (k < p.in) bv[e] = p.W[(int64_t)n * p.in + k];
-                    }
-                }
-                *reinterpret_cast<f32x4 *>(&Bs[buf][rl * LDS_STRIDE + st_c4 * 4]) = bv;
+                *reinterpret_cast<f32x4 *>(&As[buf][rl * LDS_STRIDE + st_c4 * 4]) =
+                    lin_stage_a<PRO>(p, row0 + rl, k0, trows[i], keep_scale, fast);
+                *reinterpret_cast<f32x4 *>(&Bs[buf][rl * LDS_STRIDE + st_c4 * 4]) = lin_stage_b(p, col0 + rl, k0, fast);
             }
         };
 
@@ -200,51 +239,128 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs p) {
             }
             __syncthreads();
         }
-
-        // epilogue: + bias, store (128-byte segments per half-wave), column statistics in fp64
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int col = col0 + wc * 64 + ct * 32 + r32;
-            const bool cok = col < p.out;
-            const float bj = cok ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int64_t row = row0 + wr * 64 + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    if (cok && row < p.rows) {
-                        const float v = acc[rt][ct][g] + bj;
-                        p.Y[row * p.out + col] = v;
-                        s1[ct] += (double)v;
-                        s2[ct] += (double)v * (double)v;
-                    }
-                }
-            }
-        }
+        LIN_EPILOGUE(acc[rt][ct][g])
     }
+    LIN_STATS()
+}
 
-    if (p.stats) {   // kernel-uniform
+// ---------------------------------------------------------------------------------------------
+// The same layer on the f16 matrix pipe with both operands split in two halves (large row counts: the sampler).
+//   x = hi + 2^-11 lo,  hi = f16(x),  lo = f16((x - hi) * 2^11)        |x - hi - 2^-11 lo| <= 2^-22 |x|
+//   a*w ~= hi_a hi_w + 2^-11 (hi_a lo_w + lo_a hi_w)                   (lo*lo dropped: <= 2^-22 |a||w|)
+// Three v_mfma_f32_32x32x16_f16 per 16-deep step instead of eight v_mfma_f32_32x32x2_f32: f16 products are exact in
+// the fp32 accumulator, so the result differs from the fp32 kernel's by <= ~3 * 2^-22 * sum|a||w| (fp32-class, stated
+// in DESIGN.md); the lo halves are scaled by 2^11 so that they stay normal f16 numbers and go to their own
+// accumulator, folded in once in the epilogue.  LDS rows: 32 hi halves | 32 lo halves (128 B) + 16 B pad.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define SPLIT_STRIDE 144            // bytes per LDS row
+#define SPLIT_LO_SCALE 2048.f
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4 &hi, f16x4 &lo) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            double a = s1[ct], b = s2[ct];
-            a += __shfl_xor(a, 32);
-            b += __shfl_xor(b, 32);
-            if (h == 0) { red[wid][ct][0][r32] = a; red[wid][ct][1][r32] = b; }
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hh = (_Float16)v[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)((v[e] - (float)hh) * SPLIT_LO_SCALE);
+    }
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void k_linear_split(LinArgs p) {
+    __shared__ __attribute__((aligned(16))) char As[2][BM * SPLIT_STRIDE];
+    __shared__ __attribute__((aligned(16))) char Bs[2][BN * SPLIT_STRIDE];
+    __shared__ double red[4][2][2][32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.y * BN;
+    const int nchunks = (p.in + BK - 1) / BK;
+    const int64_t ntiles = ceil_div64(p.rows, BM);
+    const float keep_scale = 1.f / (1.f - p.drop_p);
+    const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
+
+    double s1[2] = {0, 0}, s2[2] = {0, 0};
+    const int st_c4 = tid & 7, st_r = tid >> 3;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * BM;
+        f32x16 accH[2][2], accX[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { accH[a][b][g] = 0.f; accX[a][b][g] = 0.f; }
+
+        int trows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + st_r + 32 * i;
+            trows[i] = 0;
+            if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
+                trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
         }
+
+        auto stage = [&](int buf, int chunk) {
+            const int k0 = chunk * BK + st_c4 * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = st_r + 32 * i;
+                f16x4 hi, lo;
+                split4(lin_stage_a<PRO>(p, row0 + rl, k0, trows[i], keep_scale, fast), hi, lo);
+                *reinterpret_cast<f16x4 *>(&As[buf][rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&As[buf][rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
+                split4(lin_stage_b(p, col0 + rl, k0, fast), hi, lo);
+                *reinterpret_cast<f16x4 *>(&Bs[buf][rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&Bs[buf][rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
+            }
+        };
+
+        stage(0, 0);
         __syncthreads();
-        if (wr == 0 && h == 0) {
+        for (int c = 0; c < nchunks; ++c) {
+            const int cur = c & 1;
+            if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
+            // fragment of k-step u (16 deep): lane half h holds k = 16u + 8h .. + 7 of its row: one 16-byte read
+            const char *Ab = &As[cur][(wr * 64 + r32) * SPLIT_STRIDE + 16 * h];
+            const char *Bb = &Bs[cur][(wc * 64 + r32) * SPLIT_STRIDE + 16 * h];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int col = col0 + wc * 64 + ct * 32 + r32;
-                if (col < p.out) {
-                    const double a = red[wid][ct][0][r32] + red[wid + 2][ct][0][r32];
-                    const double b = red[wid][ct][1][r32] + red[wid + 2][ct][1][r32];
-                    atomicAdd(&p.stats[col], a);
-                    atomicAdd(&p.stats[p.out + col], b);
+            for (int u = 0; u < 2; ++u) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    ah[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SPLIT_STRIDE + 32 * u);
+                    al[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SPLIT_STRIDE + 64 + 32 * u);
+                    bh[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SPLIT_STRIDE + 32 * u);
+                    bl[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SPLIT_STRIDE + 64 + 32 * u);
                 }
+#pragma unroll
+                for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        accH[ra][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ra], bh[cb], accH[ra][cb], 0, 0, 0);
+                        accX[ra][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ra], bl[cb], accX[ra][cb], 0, 0, 0);
+                        accX[ra][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ra], bh[cb], accX[ra][cb], 0, 0, 0);
+                    }
             }
+            __syncthreads();
         }
+        LIN_EPILOGUE(accH[rt][ct][g] + accX[rt][ct][g] * (1.f / SPLIT_LO_SCALE))
     }
+    LIN_STATS()
+}
+
+// rows from which the split kernel serves a layer (the sampler's full-table calls); below it -- every B = 128 training
+// step, the small fixtures -- the fp32 kernel, whose arithmetic the training-trajectory pins were taken with.
+// DDG_LINEAR_F32=1 in the environment (read once) keeps the fp32 kernel everywhere (A/B timing).
+#define SPLIT_MIN_ROWS 8192
+static bool linear_force_f32() {
+    static const bool v = [] { const char *e = getenv("DDG_LINEAR_F32"); return e && e[0] == '1'; }();
+    return v;
 }
 
 static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
@@ -257,6 +373,17 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
     // row tile share an XCD, so the A rows come from HBM once and from that XCD's L2 for the other column tiles
     if (gx >= 8) gx -= gx % 8;
     dim3 grid((unsigned)gx, (unsigned)ncol);
+    if (p.rows >= SPLIT_MIN_ROWS && !linear_force_f32()) {
+        switch (prologue) {
+            case DDG_PRO_NONE: k_linear_split<DDG_PRO_NONE><<<grid, 256, 0, s>>>(p); break;
+            case DDG_PRO_ADD_EMB: k_linear_split<DDG_PRO_ADD_EMB><<<grid, 256, 0, s>>>(p); break;
+            case DDG_PRO_BN_RELU: k_linear_split<DDG_PRO_BN_RELU><<<grid, 256, 0, s>>>(p); break;
+            case DDG_PRO_EMB_RELU: k_linear_split<DDG_PRO_EMB_RELU><<<grid, 256, 0, s>>>(p); break;
+            default: return DDG_E_ARG;
+        }
+        DDG_CHECK_LAUNCH();
+        return DDG_OK;
+    }
     switch (prologue) {
         case DDG_PRO_NONE: k_linear<DDG_PRO_NONE><<<grid, 256, 0, s>>>(p); break;
         case DDG_PRO_ADD_EMB: k_linear<DDG_PRO_ADD_EMB><<<grid, 256, 0, s>>>(p); break;

@@ -730,3 +730,158 @@ extern "C" int ddg_train_disc_grads(const ddg_gen_weights *gw, const ddg_disc_we
     return ddg_train_disc_grads_dp(gw, dw, b, sched_dev, T, offsets_dev, is_cat_dev, C, loss_scale, bn_eps, grads,
                                    loss_dev, pred_out, workspace, workspace_bytes, stream, nullptr);
 }
+
+// ---------------------------------------------------------------------------------------------
+// (f4) the classifiers of the "data-dependency" plug-in            model/FD_model.py:12-65
+//
+// FDModel.forward is fc1 -> ReLU -> fc3 (fc2 is constructed and never used, :22-26); train_Model runs
+// minibatch SGD (batch 256, lr 0.02, CrossEntropyLoss) over shuffled rows (:33-52); test_model counts arg-max
+// hits (:55-65); get_my_FD_loss evaluates CrossEntropyLoss of a trained model under no_grad (:76-111).
+// One call of ddg_fd_train_epoch = one pass of the reference's inner loop over the DataLoader: the caller passes
+// the epoch's row order (its shuffle), the library walks it in batches: gather, forward, loss gradient,
+// backward, SGD update -- about a dozen short launches per batch on the fp32 MFMA.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_fd_gather(const float *__restrict__ X, const int32_t *__restrict__ Y, const int64_t *__restrict__ perm,
+                            int rows, int in, float *__restrict__ Xb, int32_t *__restrict__ Yb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * in) return;
+    const int r = e / in, k = e - r * in;
+    const int64_t src = perm[r];
+    Xb[e] = X[src * in + k];
+    if (k == 0) Yb[r] = Y[src];
+}
+__global__ void k_fd_relu(const float *__restrict__ a, int n, float *__restrict__ h) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) h[e] = fmaxf(a[e], 0.f);
+}
+// softmax / cross-entropy of one row per thread.  d_out (optional): (softmax - onehot) / rows_norm.
+// acc[0] += sum of -log softmax[y]; hits[0] += rows whose first arg-max equals y (torch.max tie rule).
+__global__ void k_fd_ce(const float *__restrict__ o, const int32_t *__restrict__ y, int rows, int out, float rows_norm,
+                        float *__restrict__ d_out, float *__restrict__ acc, int32_t *__restrict__ hits) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    int hit = 0;
+    if (r < rows) {
+        const float *p = o + (int64_t)r * out;
+        float mx = p[0];
+        int arg = 0;
+        for (int j = 1; j < out; ++j)
+            if (p[j] > mx) { mx = p[j]; arg = j; }
+        float s = 0.f;
+        for (int j = 0; j < out; ++j) s += expf(p[j] - mx);
+        const int yy = y[r];
+        l = -(p[yy] - mx - logf(s));
+        hit = arg == yy;
+        if (d_out)
+            for (int j = 0; j < out; ++j)
+                d_out[(int64_t)r * out + j] = (expf(p[j] - mx) / s - (j == yy ? 1.f : 0.f)) / rows_norm;
+    }
+    // wave reduction, one atomic per wave
+    for (int of = 32; of > 0; of >>= 1) {
+        l += __shfl_xor(l, of);
+        hit += __shfl_xor(hit, of);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (acc) atomicAdd(acc, l);
+        if (hits) atomicAdd(hits, hit);
+    }
+}
+__global__ void k_fd_sgd(float *__restrict__ p, const float *__restrict__ g, int n, float lr) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) p[e] = p[e] - lr * g[e];
+}
+
+__global__ void k_fd_mean(float *__restrict__ acc, float n) { acc[0] = acc[0] / n; }
+
+struct FdWs {
+    float *Xb, *a1, *h, *o, *dO, *dh, *da, *dW1, *db1, *dW3, *db3, *acc;
+    int32_t *Yb, *hits;
+    size_t total;
+};
+static void fd_carve(FdWs &w, char *base, int64_t B, int in, int out) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + o : nullptr; o += tal(bytes); return p; };
+    auto f = [&](size_t n) { return (float *)take(n * 4); };
+    w.Xb = f(B * in); w.a1 = f(B * in); w.h = f(B * in); w.o = f(B * out); w.dO = f(B * out); w.dh = f(B * in);
+    w.da = f(B * in); w.dW1 = f((size_t)in * in); w.db1 = f(in); w.dW3 = f((size_t)out * in); w.db3 = f(out);
+    w.acc = f(1);
+    w.Yb = (int32_t *)take(B * 4); w.hits = (int32_t *)take(4);
+    w.total = o;
+}
+extern "C" size_t ddg_fd_workspace_bytes(int64_t batch_rows, int in_dim, int out_dim) {
+    if (batch_rows < 1 || in_dim < 1 || out_dim < 1) return 0;
+    FdWs w;
+    fd_carve(w, nullptr, batch_rows, in_dim, out_dim);
+    return w.total;
+}
+static int fd_check(const ddg_fd_weights *w) {
+    if (!w || !w->W1 || !w->b1 || !w->W3 || !w->b3 || w->in_dim < 1 || w->out_dim < 1) return DDG_E_ARG;
+    return DDG_OK;
+}
+// forward of `rows` rows already in X (row-major [rows,in]): a1, h, o in the workspace
+static int fd_forward(const ddg_fd_weights *w, const float *X, int rows, FdWs &ws, void *stream) {
+    const int in = w->in_dim, out = w->out_dim;
+    int rc = ddg_linear(X, nullptr, in, w->W1, w->b1, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
+                        0, 0, ws.a1, nullptr, rows, in, in, stream);
+    if (rc) return rc;
+    k_fd_relu<<<g256((int64_t)rows * in), 256, 0, (hipStream_t)stream>>>(ws.a1, rows * in, ws.h);
+    return ddg_linear(ws.h, nullptr, in, w->W3, w->b3, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
+                      0, 0, ws.o, nullptr, rows, in, out, stream);
+}
+
+extern "C" int ddg_fd_train_epoch(const ddg_fd_weights *w, const float *X, const int32_t *Y, const int64_t *perm,
+                                  int64_t n, int batch, float lr, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+    int rc = fd_check(w);
+    if (rc) return rc;
+    if (!X || !Y || !perm || n < 0 || batch < 1 || batch > 65536) return DDG_E_ARG;
+    const int in = w->in_dim, out = w->out_dim;
+    FdWs ws;
+    fd_carve(ws, (char *)workspace, batch, in, out);
+    if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    for (int64_t r0 = 0; r0 < n; r0 += batch) {
+        const int B = (int)(n - r0 < batch ? n - r0 : batch);           // the DataLoader's last batch is ragged
+        k_fd_gather<<<g256((int64_t)B * in), 256, 0, s>>>(X, Y, perm + r0, B, in, ws.Xb, ws.Yb);
+        if ((rc = fd_forward(w, ws.Xb, B, ws, stream))) return rc;
+        k_fd_ce<<<g256(B), 256, 0, s>>>(ws.o, ws.Yb, B, out, (float)B, ws.dO, nullptr, nullptr);
+        if ((rc = gemm_dW(ws.dO, ws.h, ws.dW3, B, in, out, s))) return rc;
+        k_colsum<<<g256(out), 256, 0, s>>>(ws.dO, B, out, ws.db3);
+        if ((rc = gemm_dA(ws.dO, w->W3, ws.dh, B, in, out, s))) return rc;
+        k_relu_bwd<<<g256((int64_t)B * in), 256, 0, s>>>(ws.dh, ws.h, B * in, ws.da);
+        if ((rc = gemm_dW(ws.da, ws.Xb, ws.dW1, B, in, in, s))) return rc;
+        k_colsum<<<g256(in), 256, 0, s>>>(ws.da, B, in, ws.db1);
+        k_fd_sgd<<<g256((int64_t)in * in), 256, 0, s>>>(w->W1, ws.dW1, in * in, lr);
+        k_fd_sgd<<<g256(in), 256, 0, s>>>(w->b1, ws.db1, in, lr);
+        k_fd_sgd<<<g256((int64_t)out * in), 256, 0, s>>>(w->W3, ws.dW3, out * in, lr);
+        k_fd_sgd<<<g256(out), 256, 0, s>>>(w->b3, ws.db3, out, lr);
+    }
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+extern "C" int ddg_fd_eval(const ddg_fd_weights *w, const float *X, const int32_t *Y, int64_t n, int32_t *out_correct,
+                           float *out_ce_mean, void *workspace, size_t workspace_bytes, int64_t workspace_rows,
+                           void *stream) {
+    int rc = fd_check(w);
+    if (rc) return rc;
+    if (!X || !Y || n < 1 || workspace_rows < 1 || (!out_correct && !out_ce_mean)) return DDG_E_ARG;
+    const int in = w->in_dim, out = w->out_dim;
+    FdWs ws;
+    fd_carve(ws, (char *)workspace, workspace_rows, in, out);
+    if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws.acc, 0, 4, s) != hipSuccess || hipMemsetAsync(ws.hits, 0, 4, s) != hipSuccess) return DDG_E_LAUNCH;
+    for (int64_t r0 = 0; r0 < n; r0 += workspace_rows) {
+        const int B = (int)(n - r0 < workspace_rows ? n - r0 : workspace_rows);
+        if ((rc = fd_forward(w, X + r0 * in, B, ws, stream))) return rc;
+        k_fd_ce<<<g256(B), 256, 0, s>>>(ws.o, Y + r0, B, out, 1.f, nullptr, ws.acc, ws.hits);
+    }
+    if (out_correct && hipMemcpyAsync(out_correct, ws.hits, 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return DDG_E_LAUNCH;
+    if (out_ce_mean) {
+        k_fd_mean<<<1, 1, 0, s>>>(ws.acc, (float)n);
+        if (hipMemcpyAsync(out_ce_mean, ws.acc, 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return DDG_E_LAUNCH;
+    }
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

@@ -300,7 +300,7 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
     PG, PD = optimizer.P, discriminator_noise_x.device_params()
     widths = (PG.enc_dim, PG.lat_dim, PG.enc_dim)
     total = 0.0
-    losses = []
+    losses, fd_losses = [], []
     dp = comm is not None and comm.on
     for _ in range(timesteps):
         x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths, rank=comm.rank if dp else 0)
@@ -309,14 +309,21 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
             l = ddist.sharded_train_step(comm, ops, "G", PG, PD, optimizer, x0, Mb, mb, t, model.layout, DS.table,
                                          timesteps, loss_weight=loss_weight, **kw)
         else:
-            l, _ = ops.train_gen_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, model.layout, DS.table, timesteps,
-                                       loss_weight["Res_weight"], loss_weight["G_D_weight"], **kw)
+            want_fd = len(FDs_model_list) != 0
+            l, pred = ops.train_gen_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, model.layout, DS.table, timesteps,
+                                          loss_weight["Res_weight"], loss_weight["G_D_weight"], want_pred=want_fd, **kw)
+            if want_fd:
+                # Diffusion_FD_loss on zero_feed + (1-M) * Pred_x0 (:266-267): a constant under no_grad, reported only
+                from .FD_model import get_my_FD_loss
+                fd_losses.append(get_my_FD_loss(FDs_model_list, Mb * x0 + (1 - Mb) * pred, fields))
             optimizer.step()
         losses.append(l)
     if losses:
         ls = torch.stack(losses).double().cpu()
         total = float((ls[:, 0] * loss_weight["Res_weight"] + ls[:, 1] * loss_weight["G_D_weight"]).mean()) \
             + float(other_loss)
+        if fd_losses:
+            total += float(torch.stack(fd_losses).double().mean().cpu()) * loss_weight.get("FD_weight", 0)
     return total
 
 
@@ -398,6 +405,13 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
     widths = (optG.P.enc_dim, optG.P.lat_dim, optG.P.enc_dim)
     L_loss = 0
     r_M, b_e = 9999, 0
+    # ARMSE / AMAE of every sampling pass on the device (one pass over the missing cells) instead of a pandas decode of
+    # the whole table; the decode itself (reconvert_data) runs only for a pass that becomes the best one
+    from ..utils.util import DeviceScorer
+    try:
+        scorer = DeviceScorer(fields, value_cat, values, ori_data, data_m, enc, continuous_cols, dev)
+    except ValueError:
+        scorer = None
     for epoch in range(1, epochs + 1):
         other_loss = L_loss * loss_weight["L_weight"]
         train_one_epoch_Generator(generator_x, discriminator_noise_x, DS, x, optG, None, other_loss, epoch, epochs,
@@ -416,8 +430,11 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
                 generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout,
                                                 seed=rnd.seed, sched_host=DS.host)
             code = ops.mask_merge(x, M_tensor, generator_data, generator_x.layout)      # :598, :606-615
-            cur_r, cur_m = test_impute_data_rmse(code, fields, value_cat, values, miss_data_x.copy(), data_m, enc,
-                                                 ori_data, continuous_cols)
+            if scorer is not None:
+                cur_r, cur_m = scorer.score(code)
+            else:
+                cur_r, cur_m = test_impute_data_rmse(code, fields, value_cat, values, miss_data_x.copy(), data_m, enc,
+                                                     ori_data, continuous_cols)
             if log is not None:
                 log.append((epoch, float(cur_r), float(cur_m)))
             if use_Learner == 'True':

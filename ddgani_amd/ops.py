@@ -491,3 +491,76 @@ def learner_train(x_train, y_train, x_valid, y_valid, W, b, epochs: int, lr: flo
                                   _ptr(W, torch.float32), _ptr(b, torch.float32), _ptr(out_loss), _ptr(out_hit),
                                   ws.data_ptr(), ws.numel(), _stream()), "ddg_learner_train")
     return out_loss[0], int(out_hit.item()) / xv.shape[0]
+
+
+# ----------------------------------------------------------------------------- 8(f) row 2: column-association tables
+CODE_MISSING = 65535      # DDG_CODE_MISSING
+
+
+def contingency_tables(codes: np.ndarray, obs: np.ndarray, card: Sequence[int], device):
+    """Contingency tables of every column pair i < j over the rows observed in both (ddg_contingency; the C^2
+    ``pd.crosstab`` calls of utils/get_attr_attn.py:61-77).  codes [N,C] integer codes (host), obs [N,C] bool,
+    card[c] = number of codes of column c.  -> dict {(i, j): int64 table [card_i, card_j]} on the host."""
+    N, Cn = codes.shape
+    if max(card) >= CODE_MISSING:
+        raise _lib.DdgError("contingency_tables: more than 65534 distinct values in a column")
+    ct = np.where(obs, codes, CODE_MISSING).astype(np.uint16).T.copy()            # [C][N], column-major
+    pi, pj = np.triu_indices(Cn, k=1)
+    sizes = np.asarray(card, dtype=np.int64)[pi] * np.asarray(card, dtype=np.int64)[pj]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    dev = torch.device(device)
+    up = lambda a, dt: torch.tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+    d_ct = torch.from_numpy(ct.view(np.int16)).to(dev)
+    d_card, d_pi, d_pj, d_off = up(card, torch.int32), up(pi, torch.int32), up(pj, torch.int32), up(off, torch.int64)
+    tables = torch.empty(max(int(off[-1]), 1), dtype=torch.int32, device=dev)
+    check(lib().ddg_contingency(d_ct.data_ptr(), N, Cn, _ptr(d_card), _ptr(d_pi), _ptr(d_pj), _ptr(d_off), len(pi),
+                                int(off[-1]), tables.data_ptr(), _stream()), "ddg_contingency")
+    flat = tables.cpu().numpy().astype(np.int64)
+    return {(int(i), int(j)): flat[off[p]:off[p + 1]].reshape(card[i], card[j]) for p, (i, j) in enumerate(zip(pi, pj))}
+
+
+# ----------------------------------------------------------------------------- 8(f) row 3: decode + score on the device
+def score_table(code, ori_norm, m8, layout: FieldLayout, dec_K, dec_min, dec_f32, pos_value, norm_min, norm_den):
+    """ddg_score_table -> sums [C,3] fp64 on the device (sum d^2, sum |d|, mismatches over the missing cells)."""
+    N, D = code.shape
+    off, cat = layout.on(code.device)
+    sums = torch.zeros(layout.C, 3, dtype=torch.float64, device=code.device)
+    check(lib().ddg_score_table(_ptr(code, torch.float32), _ptr(ori_norm, torch.float64), _ptr(m8, torch.uint8), _ptr(off),
+                                _ptr(cat), _ptr(dec_K, torch.float64), _ptr(dec_min, torch.float64),
+                                _ptr(dec_f32, torch.uint8), _ptr(pos_value, torch.float64), _ptr(norm_min, torch.float64),
+                                _ptr(norm_den, torch.float64), _ptr(sums), N, layout.C, D, _stream()), "ddg_score_table")
+    return sums
+
+
+# ----------------------------------------------------------------------------- 8(f) row 4: FD classifiers
+class FdParams:
+    """Device tensors of an FDModel's used layers (fc1, fc3: model/FD_model.py:15-26), updated in place by
+    ddg_fd_train_epoch."""
+
+    def __init__(self, W1, b1, W3, b3):
+        self.W1, self.b1, self.W3, self.b3 = [t.detach().to(torch.float32).contiguous() for t in (W1, b1, W3, b3)]
+        self.in_dim, self.out_dim = self.W1.shape[0], self.W3.shape[0]
+        if self.W1.shape != (self.in_dim, self.in_dim) or self.W3.shape[1] != self.in_dim:
+            raise _lib.DdgError("FdParams: fc1 must be [in,in] and fc3 [out,in]")
+        self.c = _lib.FdWeights(self.in_dim, self.out_dim, self.W1.data_ptr(), self.b1.data_ptr(), self.W3.data_ptr(),
+                                self.b3.data_ptr())
+
+
+def fd_train_epoch(P: FdParams, X, Y, perm, batch: int = 256, lr: float = 0.02):
+    """one epoch of train_Model (model/FD_model.py:41-46) over the rows of X in the order ``perm`` (int64, device)"""
+    n = perm.numel()
+    ws = _workspace(lib().ddg_fd_workspace_bytes(batch, P.in_dim, P.out_dim), X.device, "fd")
+    check(lib().ddg_fd_train_epoch(C.byref(P.c), _ptr(X, torch.float32), _ptr(Y, torch.int32), _ptr(perm, torch.int64), n,
+                                   int(batch), float(lr), ws.data_ptr(), ws.numel(), _stream()), "ddg_fd_train_epoch")
+
+
+def fd_eval(P: FdParams, X, Y, chunk_rows: int = 65536):
+    """-> (correct: 0-dim int32 device tensor, ce_mean: 0-dim float device tensor) of the model on (X, Y)"""
+    n = X.shape[0]
+    rows = min(n, chunk_rows)
+    ws = _workspace(lib().ddg_fd_workspace_bytes(rows, P.in_dim, P.out_dim), X.device, "fd")
+    hit = torch.empty(1, dtype=torch.int32, device=X.device)
+    ce = torch.empty(1, dtype=torch.float32, device=X.device)
+    check(lib().ddg_fd_eval(C.byref(P.c), _ptr(X, torch.float32), _ptr(Y, torch.int32), n, _ptr(hit), _ptr(ce),
+                            ws.data_ptr(), ws.numel(), rows, _stream()), "ddg_fd_eval")
+    return hit[0], ce[0]

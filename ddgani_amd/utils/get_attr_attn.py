@@ -85,6 +85,23 @@ def association_map(codes: np.ndarray, data_m: np.ndarray) -> np.ndarray:
     return np.abs(out)
 
 
+def association_map_device(codes: np.ndarray, data_m: np.ndarray, device) -> np.ndarray:
+    """``association_map`` with the C^2 contingency tables counted on the GPU (ddg_contingency: one pass per column
+    pair over the co-observed rows); the chi-square / Cramer's-V arithmetic on each small table is the same host code,
+    so the map is bit-identical to ``association_map``."""
+    from .. import ops
+    n, C = codes.shape
+    obs = np.asarray(data_m) == 1
+    card = (codes.max(axis=0) + 1).astype(np.int64).tolist() if n else [1] * C
+    tabs = ops.contingency_tables(codes, obs, card, device)
+    out = np.zeros((C, C), dtype=np.float64)
+    for (i, j), t in tabs.items():
+        t = t[t.sum(axis=1) > 0][:, t.sum(axis=0) > 0]                  # crosstab keeps seen labels only
+        out[j, i] = cramers_v_table(t)
+        out[i, j] = cramers_v_table(np.ascontiguousarray(t.T))
+    return np.abs(out)
+
+
 def get_tongji_attn_map(impute_data, method, isNull):
     """reference: utils/get_attr_attn.py:21-33."""
     corr = impute_data if isNull else impute_data.corr(method=method)
@@ -93,8 +110,11 @@ def get_tongji_attn_map(impute_data, method, isNull):
     return np.abs(v)
 
 
-def get_attr_map_Null_kendall(pathMiss, data_m, categorical_cols, continuous_cols):
-    """reference: utils/get_attr_attn.py:35-80 -> corr_map [C,C] float64."""
+def get_attr_map_Null_kendall(pathMiss, data_m, categorical_cols, continuous_cols, device=None):
+    """reference: utils/get_attr_attn.py:35-80 -> corr_map [C,C] float64.  ``device`` (extension): a GPU device
+    counts the contingency tables there (same map, bit for bit); None keeps the host bincount path."""
     Miss_data = pd.read_csv(pathMiss)
     codes = discretise(Miss_data, continuous_cols)
+    if device is not None and str(device).startswith("cuda"):
+        return association_map_device(codes, data_m, device)
     return association_map(codes, data_m)

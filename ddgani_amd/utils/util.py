@@ -147,6 +147,75 @@ def test_impute_data_rmse(x_code, fields, value_cat, values, miss_data_x, data_m
     return errorLoss(impute_data, ori_data, data_m, value_cat, continuous_cols, enc)
 
 
+class DeviceScorer:
+    """``test_impute_data_rmse`` (utils/util.py:648-658 = reconvert_data + errorLoss) for encoded tables that live on
+    the GPU: everything that does not depend on the table being scored -- the normalised ground truth, the decode
+    constants of the fields, the missing-cell counts -- is prepared once; ``score(code)`` is then one pass over the
+    missing cells on the device (ddg_score_table) and a C-element finish on the host, instead of a pandas round trip of
+    the whole table per sampling pass (model/Diffusion.py:617)."""
+
+    def __init__(self, fields, value_cat, values, ori_data, data_m, enc, continuous_cols, device):
+        from .. import ops
+        ori = ori_data.copy()
+        if len(value_cat) != 0:
+            ori[value_cat] = enc.transform(ori[value_cat])
+        ori = np.nan_to_num(ori.values.astype(float))
+        ori_n, par = normalization(ori)
+        widths = field_widths(fields)
+        C = len(fields)
+        self.layout = ops.FieldLayout(widths, device)
+        is_num = np.zeros(C, dtype=bool)
+        is_num[list(continuous_cols)] = True
+        if not np.array_equal(is_num, np.asarray(widths) == 1):
+            # a categorical column with a single distinct value (or a numeric one encoded wider) cannot be told apart
+            # by width on the device
+            raise ValueError("DeviceScorer: numeric columns must be exactly the width-1 fields")
+        K = np.ones(C)
+        mn = np.zeros(C)
+        f32 = np.zeros(C, dtype=np.uint8)
+        pos = np.zeros(sum(widths))
+        a = 0
+        for c, f in enumerate(fields):
+            if widths[c] == 1:
+                K[c], mn[c] = float(f.K), float(f.Min)
+                # NumericalField.reverse is ``features / K + Min`` on the fp32 code: numpy keeps fp32 when K and Min are
+                # Python floats (learnt from an object-typed column) and promotes to fp64 for numpy float64 scalars
+                weak = [not isinstance(v, np.generic) for v in (f.K, f.Min)]
+                if weak[0] != weak[1]:
+                    raise ValueError("DeviceScorer: K and Min of a field have different scalar kinds")
+                f32[c] = 1 if weak[0] else 0
+            else:
+                pos[a:a + widths[c]] = np.asarray(f._values, dtype=float)
+            a += widths[c]
+        up = lambda v: torch.tensor(np.ascontiguousarray(v), dtype=torch.float64).to(device)
+        m = np.asarray(data_m)
+        self.m8 = torch.tensor(m != 0, dtype=torch.uint8).to(device)
+        self.ori_n, self.K, self.mn, self.pos = up(ori_n), up(K), up(mn), up(pos)
+        self.f32 = torch.tensor(f32).to(device)
+        self.nmin, self.nden = up(par["min_val"]), up(par["max_val"] + 1e-6)
+        self.n_miss = (1.0 - m.astype(float)).sum(axis=0)
+        self.is_num = is_num
+
+    def score(self, code: torch.Tensor):
+        """-> (ARMSE, AMAE) of the encoded table ``code`` [N,D] (fp32, on the scorer's device)."""
+        from .. import ops
+        s = ops.score_table(code.contiguous(), self.ori_n, self.m8, self.layout, self.K, self.mn, self.f32, self.pos, self.nmin,
+                            self.nden).cpu().numpy()
+        armse = amae = 0.0
+        used = 0
+        for i in range(len(self.n_miss)):
+            if self.n_miss[i] == 0:
+                continue
+            if self.is_num[i]:
+                armse += np.sqrt(s[i, 0] / self.n_miss[i])
+                amae += s[i, 1] / self.n_miss[i]
+            else:
+                armse += s[i, 2] / self.n_miss[i]
+                amae += s[i, 2] / self.n_miss[i]
+            used += 1
+        return armse / used, amae / used
+
+
 def sort_corr(corr_map):
     """reference: utils/util.py:692-697: per column, the other columns by descending weight
     (stable, like ``sorted(..., reverse=True)``)."""
@@ -181,9 +250,12 @@ def attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_c
 
 
 def topk_count(n_rows: int, top_k) -> int:
-    """k of the reference (utils/util.py:459): ``int(N * top_k)`` for a fraction; a value >= 1 is an
-    absolute count (extension needed by BASELINE.json config 3, "top_k=10")."""
-    return int(top_k) if top_k >= 1 else int(n_rows * top_k)
+    """k of the reference (utils/util.py:459): ``int(N * top_k)``.  Extension needed by BASELINE.json config 3
+    ("top_k=10"): an INTEGER top_k >= 1 (``"top_k": 10`` in param.json) is an absolute count; any float, 1.0
+    included, is the reference's fraction."""
+    if isinstance(top_k, (int, np.integer)) and not isinstance(top_k, bool) and top_k >= 1:
+        return int(top_k)
+    return int(n_rows * top_k)
 
 
 def init_attn_2(corr_map, miss_data, data_m, categorical_cols, enc, value_cat, device, top_k):
@@ -191,8 +263,20 @@ def init_attn_2(corr_map, miss_data, data_m, categorical_cols, enc, value_cat, d
     [N,D] on ``device``).  The C dense N x N softmax / top-k matrices of the reference
     (:449-466, :484-496) are replaced by one call of the streaming HIP kernel."""
     if corr_map is None:
-        raise NotImplementedError("init_attn_2(corr_map=None): the unweighted variant (utils/util.py:467-476) is "
-                                  "not on the DDGANI path (BaseLine/DiffGANI.py:21 always passes a map)")
+        # The reference's unweighted branch (utils/util.py:467-476) takes ``topk(...).values[:, -1]`` (wrong axis: a
+        # [k] vector of the LAST query's k largest probabilities) and expands it to [N, N]: torch raises
+        # "The expanded size of the tensor (N) must match the existing size (k)" for every 1 < k < N, i.e. for every
+        # top_k the reference is configured with.  Same error behaviour here.  Only k == 1 and k == N pass that line in
+        # the reference; their result is an artefact of the wrong axis and is not on the DDGANI path
+        # (BaseLine/DiffGANI.py:21 always passes a map).
+        n = len(miss_data)
+        k = int(n * top_k)
+        if 1 < k < n:
+            raise RuntimeError(f"The expanded size of the tensor ({n}) must match the existing size ({k}) at non-singleton "
+                               f"dimension 0.  Target sizes: [{n}, {n}].  Tensor sizes: [{k}, 1]  (init_attn_2 with "
+                               "corr_map=None fails here in the reference too: utils/util.py:472-473)")
+        raise NotImplementedError("init_attn_2(corr_map=None) with int(N*top_k) in {0, 1, N}: degenerate cases of the "
+                                  "reference's unweighted branch (utils/util.py:467-476) are not built")
     from .. import ops
     values = miss_data.columns
     fields, X, M, W, widths = attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat)

@@ -364,6 +364,65 @@ int ddg_learner_train(const float *x_train, const int32_t *y_train, int64_t n_tr
                       int epochs, float lr, float *W, float *b, float *out_val_loss,
                       int32_t *out_val_correct, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * (f4) classifiers of the "data-dependency" plug-in   model/FD_model.py:12-65, :76-111
+ *
+ * FDModel.forward = fc1 [in,in] -> ReLU -> fc3 [out,in] (fc2 exists but is never used, :22-26).
+ *   ddg_fd_train_epoch  one pass of train_Model's inner loop (:41-46): SGD (lr, CrossEntropyLoss mean) over the
+ *                       rows of X in the order perm[0..n) (the DataLoader's shuffle of this epoch, int64 on the
+ *                       device), `batch` rows per step (256 in the reference), last batch ragged; W1/b1/W3/b3 are
+ *                       updated in place.
+ *   ddg_fd_eval         test_model (:55-65): out_correct = rows whose arg-max equals Y;  get_my_FD_loss's term
+ *                       (:106-108): out_ce_mean = CrossEntropyLoss(model(X), Y) (mean).  Either output may be NULL.
+ *                       Rows are processed workspace_rows at a time (the workspace is sized for that many).
+ * X [n,in] fp32, Y int32 [n] class indices in [0,out).  Workspace: ddg_fd_workspace_bytes(rows per step, in, out).
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddg_fd_weights {
+    int32_t in_dim, out_dim;
+    float *W1, *b1, *W3, *b3;
+} ddg_fd_weights;
+size_t ddg_fd_workspace_bytes(int64_t batch_rows, int in_dim, int out_dim);
+int ddg_fd_train_epoch(const ddg_fd_weights *w, const float *X, const int32_t *Y, const int64_t *perm, int64_t n,
+                       int batch, float lr, void *workspace, size_t workspace_bytes, void *stream);
+int ddg_fd_eval(const ddg_fd_weights *w, const float *X, const int32_t *Y, int64_t n, int32_t *out_correct,
+                float *out_ce_mean, void *workspace, size_t workspace_bytes, int64_t workspace_rows, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (f2) column-association map: the C^2 crosstabs of get_attr_map_Null_kendall
+ *                                                   utils/get_attr_attn.py:61-77 (pd.crosstab per column pair)
+ *
+ * codes_t: uint16 [C][N], COLUMN-major: the discretised table (20-bin numerics :49-51, ordinal categoricals :54),
+ * DDG_CODE_MISSING where data_m == 0 (the reference drops those rows per pair, :66-70).  card [C]: codes of column
+ * c lie in [0, card[c]).  For every listed pair p = (pair_i[p], pair_j[p]) the contingency table
+ *   tables[pair_off[p] + a * card[j] + b] = #{rows r : codes[i][r] == a, codes[j][r] == b, both observed}
+ * total_cells = pair_off[n_pairs].  All arrays on the device.  The chi-square / Cramer's-V arithmetic on the
+ * tables (:9-18) stays on the host (ddgani_amd/utils/get_attr_attn.py): C^2 tiny tables.
+ * ------------------------------------------------------------------------------------- */
+#define DDG_CODE_MISSING 65535u
+int ddg_contingency(const uint16_t *codes_t, int64_t N, int C, const int32_t *card_dev, const int32_t *pair_i_dev,
+                    const int32_t *pair_j_dev, const int64_t *pair_off_dev, int64_t n_pairs, int64_t total_cells,
+                    uint32_t *tables, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (f3) decode + score of an encoded table: reconvert_data   utils/util.py:228-254
+ *                                           errorLoss       utils/util.py:83-139 (normalization :17-48)
+ *
+ * One pass over the MISSING cells (m == 0) of code [N,D]: decode (numeric x / K + Min, utils/field.py:75-82, in the
+ * arithmetic numpy uses for it: dec_f32[c] = 1 when the field's K / Min are Python floats (object-typed column: the
+ * fp32 code stays fp32), 0 when they are numpy float64 (fp64); categorical: value of the arg-max position, first
+ * maximum), normalise with the ground
+ * truth's (min, max + 1e-6), and add per column into sums [C][3] (fp64; zero it first):
+ *   [c][0] sum d^2, [c][1] sum |d|   (numeric columns),   [c][2] cells that differ (categorical columns)
+ * with d = ori_norm[r,c] - normalised decoded value.  ori_norm [N,C] fp64: the normalised ground truth.
+ * dec_K / dec_min / norm_min / norm_den: fp64 [C]; pos_value: fp64 [D] value of every one-hot position.
+ * ARMSE / AMAE = means over the columns with missing cells of sqrt(sum d^2 / n_miss) resp. sum |d| / n_miss,
+ * categorical columns contributing their mismatch rate to both (utils/util.py:112-139): finished on the host.
+ * ------------------------------------------------------------------------------------- */
+int ddg_score_table(const float *code, const double *ori_norm, const uint8_t *m, const int32_t *offsets_dev,
+                    const uint8_t *is_cat_dev, const double *dec_K, const double *dec_min, const uint8_t *dec_f32,
+                    const double *pos_value, const double *norm_min, const double *norm_den, double *sums, int64_t N,
+                    int C, int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,3 +402,62 @@ def test_attn_other_configs_modes_agree(dev, wl, rows):
     (o1, t1, n1), (o0, t0, n0) = res
     assert torch.equal(n1, n0)
     _assert_modes_agree(tab, lo, (o1, t1), (o0, t0), dev)
+
+
+# ----------------------------------------------------------------------------- split-precision layers (large row counts)
+def test_linear_split_kernel_is_fp32_class(dev):
+    """From 8 192 rows on, ddg_linear runs on the f16 matrix pipe with both operands split in two halves
+    (csrc/gemm.hip: k_linear_split; error <= ~3 * 2^-22 * sum|a||w|).  Against an fp64 product: every prologue, the
+    concatenated operand of the discriminator, widths that are not multiples of the tile, tiny and large magnitudes;
+    and the fp32 kernel (below the row threshold) on the same rows for comparison."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    N = 20000
+    for (din, dout) in ((176, 352), (352, 176), (57, 114), (290, 72)):
+        A = torch.randn(N, din, generator=g) * torch.logspace(-4, 1, din)          # columns from 1e-4 to 10
+        W = (torch.rand(dout, din, generator=g) - 0.5) * 0.15
+        b = torch.randn(dout, generator=g) * 0.1
+        ref = A.double() @ W.double().T + b.double()
+        bound = (A.double().abs() @ W.double().abs().T)                             # sum |a||w| per output
+        got = ops.linear(A.to(dev), W.to(dev), b.to(dev)).cpu().double()
+        err = ((got - ref).abs() / bound.clamp_min(1e-30)).max().item()
+        assert err < 1.5e-6, (din, dout, err)                                       # 3 * 2^-22 = 7e-7 plus fp32 accumulation
+        small = ops.linear(A[:4096].to(dev), W.to(dev), b.to(dev)).cpu().double()   # fp32 kernel
+        assert (small - got[:4096]).abs().max().item() < 2e-6 * bound.max().item()
+        # column statistics of the split kernel's output
+        stats = torch.zeros(2 * dout, dtype=torch.float64, device=dev)
+        y = ops.linear(A.to(dev), W.to(dev), b.to(dev), stats=stats)
+        assert torch.allclose(stats[:dout].cpu(), y.double().sum(0).cpu(), rtol=1e-12, atol=1e-9)
+        assert torch.allclose(stats[dout:].cpu(), (y.double() ** 2).sum(0).cpu(), rtol=1e-12, atol=1e-9)
+    # concatenated operand + per-row embedding prologue (discriminator layers) at large N
+    z = load("sampler_mixed")
+    sd = state_dict(z, "D__")
+    P = ops.DiscParams(sd, dev)
+    D = P.in_dim // 2
+    a, b2 = torch.randn(N, D, generator=g), torch.randn(N, D, generator=g)
+    t = torch.randint(2, int(z["T"]) + 1, (N,), generator=g)
+    with torch.no_grad():
+        ref = orc.disc_forward(sd, a, b2, t)
+    out = ops.disc_fwd(P, a.to(dev), b2.to(dev), t.to(dev))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-6)
+
+
+def test_denoiser_large_rows_split_path(dev):
+    """the whole denoiser (BatchNorm / ReLU / dropout prologues) at 20 000 rows -- the split kernels -- against the
+    oracle, same bar as the small fixtures (1e-5)"""
+    ops = _ops()
+    z = load("train_mixed")
+    T = int(z["T"])
+    lay = ops.FieldLayout(z["widths"].tolist(), dev)
+    sd = state_dict(z, "G0__")
+    P = ops.GenParams(sd, dev)
+    off, cat = layout_of(z["widths"])
+    g = torch.Generator().manual_seed(6)
+    N = 20000
+    x = torch.rand(N, lay.D, generator=g)
+    t = torch.randint(2, T + 1, (N,), generator=g)
+    masks = [torch.rand(N, w, generator=g) < 0.8 for w in (2 * lay.D, lay.D, 2 * lay.D)]
+    with torch.no_grad():
+        ref = orc.generator_forward(sd, x, t, off, cat, [m.float() / 0.8 for m in masks])
+    out = ops.denoiser_fwd(P, x.to(dev), t.to(dev), lay, drops=[m.to(torch.uint8).to(dev) for m in masks])
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-5)

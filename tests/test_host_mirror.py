@@ -123,3 +123,17 @@ def test_field_protocol_and_errors():
         c.convert(np.array([7.0]))
     with pytest.raises(ValueError):
         NumericalField("gmm")
+
+
+def test_init_attn_2_without_map_fails_like_the_reference():
+    """init_attn_2(corr_map=None): the reference's unweighted branch raises RuntimeError at its expand_as for every
+    1 < int(N*top_k) < N (probed on the reference: top_k 0.05 and 0.2 on a 60-row table); so does the mirror."""
+    from ddgani_amd.utils import util
+    rng = np.random.default_rng(0)
+    df = pd.DataFrame({"a": rng.normal(size=60), "b": rng.normal(size=60), "c": rng.normal(size=60)})
+    dm = pd.DataFrame((rng.uniform(size=(60, 3)) < 0.8).astype(int))
+    for tk, k in ((0.05, 3), (0.2, 12)):
+        with pytest.raises(RuntimeError, match=rf"must match the existing size \({k}\)"):
+            util.init_attn_2(None, df.copy(), dm, [], None, [], torch.device("cpu"), tk)
+    with pytest.raises(NotImplementedError):
+        util.init_attn_2(None, df.copy(), dm, [], None, [], torch.device("cpu"), 1.0)
