@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="override the workload's row count (0 = as named)")
     ap.add_argument("--attn-mode", default="bf16filter", choices=["f32", "bf16filter"],
                     help="similarity arithmetic of the attention fill (include/ddgani.h: DDG_ATTN_*)")
+    ap.add_argument("--topk", type=float, default=0.0,
+                    help="override the workload's top_k: a value < 1 is the reference's fraction of N (param.json uses "
+                         "0.05), a value >= 1 an absolute count; 0 = as the workload names it")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                      "multi-rank path on a one-GPU box together with --one-device)")
@@ -161,6 +164,8 @@ def main():
     N = a.rows or wl["rows"]
     tab = synth.make_table(a.workload, dev, rows=N)      # every rank builds the same table, keeps its shard
     lay, k, T = tab.layout, tab.k, tab.T
+    if a.topk > 0:
+        k = int(a.topk) if a.topk >= 1 else max(1, int(N * a.topk))
     comm = ddist.Comm()
     lo, hi = ddist.shard_bounds(N, comm.world)[comm.rank]
     Xq = tab.X_attn[lo:hi].contiguous()
@@ -178,7 +183,7 @@ def main():
     out_code = torch.empty_like(Xq)
     merged = torch.empty_like(xd)
     sched_host = ops.schedule(T)
-    amode = ops.ATTN_BF16_FILTER if (a.attn_mode == "bf16filter" and k <= ops.MAX_TOPK_REG) else ops.ATTN_F32
+    amode = ops.ATTN_BF16_FILTER if a.attn_mode == "bf16filter" else ops.ATTN_F32
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     sel_ms, fill_ms, prep_ms, samp_ms = [], [], [], []
@@ -244,7 +249,7 @@ def main():
         n_launch = 1 if k <= ops.MAX_TOPK_REG else 5                      # radix select = 5 launches of the same kernel
         flops = 2.0 * lay.D * pairs_local
         achieved = flops / (sel / n_launch * 1e-3) / 1e12
-        filt = amode == ops.ATTN_BF16_FILTER
+        filt = amode == ops.ATTN_BF16_FILTER and k <= ops.MAX_TOPK_REG      # larger k: fp32 radix select in either mode
         kname = ("void k_attn_screen<", "void k_attn_rescore<", "void k_attn_warm<") if filt else "void k_attn<"
         peak = PEAK_BF16_MFMA_TFLOPS if filt else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = pmc_traffic(a.workload, N, kname) if world == 1 else (None, None)
@@ -262,6 +267,7 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("k_attn_screen (bf16 MFMA similarity screening; its time here includes the exact fp32 "
                                     "k_attn_rescore and k_attn_warm launches of the select phase, about 12 % of it)" if filt else
+                                    "k_attn<MODE_HIST> (fp32 MFMA similarity, 5-level radix select of the k-th logit)" if k > ops.MAX_TOPK_REG else
                                     "k_attn<MODE_TOPK> (fp32 MFMA similarity + top-k + fill)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": flops, "launch_ms": sel / n_launch,

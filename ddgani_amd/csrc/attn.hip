@@ -27,6 +27,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 #define QPB 128          // queries per block
@@ -1307,10 +1308,17 @@ struct AttnWs {
 // prefix before it yields about k+1 candidates per query; the cap keeps a chunk's bf16 rows inside the
 // Infinity Cache.  DDG_FILT_CHUNK (multiple of 128) forces a fixed chunk length: tests use a small one.
 #define FILT_CHUNK_MAX 262144       // <= 65536 tiles of 32 keys: the tile number of a candidate word has 16 bits
-static int64_t filt_chunk_fixed() {       // read per call: tests switch schedules inside one process
+// The environment is read ONCE per process (production calls never touch getenv again); DDG_FILT_CHUNK_RELOAD=1, set
+// before the first call, makes every call re-read it (the parity tests switch schedules inside one process).
+static int64_t filt_chunk_parse() {
     const char *e = getenv("DDG_FILT_CHUNK");
     const int64_t c = e ? atoll(e) : 0;
     return c <= 0 ? 0 : (c < 128 ? 128 : (c / 128) * 128);
+}
+static int64_t filt_chunk_fixed() {
+    static const bool reload = [] { const char *e = getenv("DDG_FILT_CHUNK_RELOAD"); return e && e[0] == '1'; }();
+    static const int64_t once = filt_chunk_parse();
+    return reload ? filt_chunk_parse() : once;
 }
 
 static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int D, int64_t k, bool same) {
@@ -1364,15 +1372,17 @@ extern "C" size_t ddg_attn_workspace_bytes(int64_t Nq, int64_t Nk, int C, int D,
     return w.total;
 }
 
-static int set_lds_attr(const void *fn, size_t lds, size_t &granted) {
+// `granted`: the largest dynamic-LDS size already opted into for this kernel (per kernel instantiation; atomic: entry
+// points may be called from several host threads -- setting the attribute twice is harmless, a torn read is not)
+static int set_lds_attr(const void *fn, size_t lds, std::atomic<size_t> &granted) {
     if (lds > 160 * 1024 - 64) return DDG_E_UNSUPPORTED;
-    if (lds > granted) {   // dynamic LDS above the default limit must be opted into
+    if (lds > granted.load(std::memory_order_acquire)) {   // dynamic LDS above the default limit must be opted into
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             fprintf(stderr, "ddgani: hipFuncSetAttribute(%zu): %s\n", lds, hipGetErrorString(e));
             return DDG_E_LAUNCH;
         }
-        granted = lds;
+        granted.store(lds, std::memory_order_release);
     }
     return DDG_OK;
 }
@@ -1380,7 +1390,7 @@ static int set_lds_attr(const void *fn, size_t lds, size_t &granted) {
 template <int KS4, int MODE, int KCAP>
 static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_bytes, hipStream_t s) {
     const size_t lds = (size_t)2 * TK * (KS4 * 8 + 4) * 4 + extra_bytes;
-    static size_t granted = 48 * 1024;
+    static std::atomic<size_t> granted{48 * 1024};
     int rc = set_lds_attr((const void *)k_attn<KS4, MODE, KCAP>, lds, granted);
     if (rc) return rc;
     k_attn<KS4, MODE, KCAP><<<(unsigned)nblocks_max, 256, lds, s>>>(a);
@@ -1392,7 +1402,7 @@ template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
     const size_t lds = (size_t)3 * screen_stage_keys(KS) * (KS * 32);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
-    static size_t granted = 48 * 1024, granted_w = 48 * 1024;
+    static std::atomic<size_t> granted{48 * 1024}, granted_w{48 * 1024};
     int rc = set_lds_attr((const void *)k_attn_screen<KS>, lds, granted);
     if (rc) return rc;
     if ((rc = set_lds_attr((const void *)k_attn_warm<KS * 2, KCAP>, lds_w, granted_w))) return rc;

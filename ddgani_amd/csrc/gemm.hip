@@ -267,10 +267,15 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4 &hi, f16x4 &lo) {
     }
 }
 
-template <int PRO>
-__global__ __launch_bounds__(256, 2) void k_linear_split(LinArgs p) {
-    __shared__ __attribute__((aligned(16))) char As[2][BM * SPLIT_STRIDE];
-    __shared__ __attribute__((aligned(16))) char Bs[2][BN * SPLIT_STRIDE];
+// RT = 32-row tiles per wave along M: block tile (64 RT) x 128.  RT = 1 halves the accumulators (64 registers for the
+// hi and the cross sums together), which lets four workgroups share a CU: the layer is bound by the latency of the
+// operand loads (K is only 176 / 352 deep, a chunk's MFMAs last ~0.35 us), so more waves in flight is what pays.
+// One LDS buffer; the next chunk's global loads are in flight in registers while the current chunk is multiplied.
+template <int PRO, int RT>
+__global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs p) {
+    constexpr int BMS = 64 * RT;
+    __shared__ __attribute__((aligned(16))) char As[BMS * SPLIT_STRIDE];
+    __shared__ __attribute__((aligned(16))) char Bs[BN * SPLIT_STRIDE];
     __shared__ double red[4][2][2][32];
 
     const int tid = threadIdx.x;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(LinArgs p) {
     const int r32 = lane & 31, h = lane >> 5;
     const int col0 = blockIdx.y * BN;
     const int nchunks = (p.in + BK - 1) / BK;
-    const int64_t ntiles = ceil_div64(p.rows, BM);
+    const int64_t ntiles = ceil_div64(p.rows, BMS);
     const float keep_scale = 1.f / (1.f - p.drop_p);
     const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
 
@@ -287,59 +292,75 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(LinArgs p) {
     const int st_c4 = tid & 7, st_r = tid >> 3;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * BM;
-        f32x16 accH[2][2], accX[2][2];
+        const int64_t row0 = tile * BMS;
+        f32x16 accH[RT][2], accX[RT][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RT; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { accH[a][b][g] = 0.f; accX[a][b][g] = 0.f; }
 
-        int trows[4];
+        int trows[2 * RT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * RT; ++i) {
             const int64_t row = row0 + st_r + 32 * i;
             trows[i] = 0;
             if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
                 trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
         }
 
-        auto stage = [&](int buf, int chunk) {
+        f32x4 pa[2 * RT], pb[4];
+        auto fetch = [&](int chunk) {
             const int k0 = chunk * BK + st_c4 * 4;
+#pragma unroll
+            for (int i = 0; i < 2 * RT; ++i)
+                pa[i] = lin_stage_a<PRO>(p, row0 + st_r + 32 * i, k0, trows[i], keep_scale, fast);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb[i] = lin_stage_b(p, col0 + st_r + 32 * i, k0, fast);
+        };
+        auto commit = [&]() {
+            f16x4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 2 * RT; ++i) {
+                const int rl = st_r + 32 * i;
+                split4(pa[i], hi, lo);
+                *reinterpret_cast<f16x4 *>(&As[rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&As[rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rl = st_r + 32 * i;
-                f16x4 hi, lo;
-                split4(lin_stage_a<PRO>(p, row0 + rl, k0, trows[i], keep_scale, fast), hi, lo);
-                *reinterpret_cast<f16x4 *>(&As[buf][rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
-                *reinterpret_cast<f16x4 *>(&As[buf][rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
-                split4(lin_stage_b(p, col0 + rl, k0, fast), hi, lo);
-                *reinterpret_cast<f16x4 *>(&Bs[buf][rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
-                *reinterpret_cast<f16x4 *>(&Bs[buf][rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
+                split4(pb[i], hi, lo);
+                *reinterpret_cast<f16x4 *>(&Bs[rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&Bs[rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
             }
         };
 
-        stage(0, 0);
-        __syncthreads();
+        fetch(0);
         for (int c = 0; c < nchunks; ++c) {
-            const int cur = c & 1;
-            if (c + 1 < nchunks) stage(cur ^ 1, c + 1);
+            __syncthreads();                       // the previous chunk's fragment reads are done
+            commit();
+            if (c + 1 < nchunks) fetch(c + 1);     // in flight while this chunk is multiplied
+            __syncthreads();
             // fragment of k-step u (16 deep): lane half h holds k = 16u + 8h .. + 7 of its row: one 16-byte read
-            const char *Ab = &As[cur][(wr * 64 + r32) * SPLIT_STRIDE + 16 * h];
-            const char *Bb = &Bs[cur][(wc * 64 + r32) * SPLIT_STRIDE + 16 * h];
+            const char *Ab = &As[(wr * 32 * RT + r32) * SPLIT_STRIDE + 16 * h];
+            const char *Bb = &Bs[(wc * 64 + r32) * SPLIT_STRIDE + 16 * h];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                f16x8 ah[2], al[2], bh[2], bl[2];
+                f16x8 ah[RT], al[RT], bh[2], bl[2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < RT; ++q) {
                     ah[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SPLIT_STRIDE + 32 * u);
                     al[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SPLIT_STRIDE + 64 + 32 * u);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
                     bh[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SPLIT_STRIDE + 32 * u);
                     bl[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SPLIT_STRIDE + 64 + 32 * u);
                 }
 #pragma unroll
-                for (int ra = 0; ra < 2; ++ra)
+                for (int ra = 0; ra < RT; ++ra)
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         accH[ra][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ra], bh[cb], accH[ra][cb], 0, 0, 0);
@@ -347,9 +368,27 @@ __global__ __launch_bounds__(256, 2) void k_linear_split(LinArgs p) {
                         accX[ra][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ra], bh[cb], accX[ra][cb], 0, 0, 0);
                     }
             }
-            __syncthreads();
         }
-        LIN_EPILOGUE(accH[rt][ct][g] + accX[rt][ct][g] * (1.f / SPLIT_LO_SCALE))
+        // epilogue: + bias, store, fp64 column statistics
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = col0 + wc * 64 + ct * 32 + r32;
+            const bool cok = col < p.out;
+            const float bj = cok ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int64_t row = row0 + wr * 32 * RT + rt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (cok && row < p.rows) {
+                        const float v = accH[rt][ct][g] + accX[rt][ct][g] * (1.f / SPLIT_LO_SCALE) + bj;
+                        p.Y[row * p.out + col] = v;
+                        s1[ct] += (double)v;
+                        s2[ct] += (double)v * (double)v;
+                    }
+                }
+            }
+        }
     }
     LIN_STATS()
 }
@@ -374,13 +413,24 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
     if (gx >= 8) gx -= gx % 8;
     dim3 grid((unsigned)gx, (unsigned)ncol);
     if (p.rows >= SPLIT_MIN_ROWS && !linear_force_f32()) {
+        static const int rt = [] { const char *e = getenv("DDG_SPLIT_RT"); return (e && e[0] == '2') ? 2 : 1; }();
+        const int64_t nt = ceil_div64(p.rows, 64 * rt);
+        int64_t g = nt;
+        const int64_t cap2 = (256 * (rt == 1 ? 3 : 2) + ncol - 1) / ncol;
+        if (g > cap2) g = cap2;
+        if (g >= 8) g -= g % 8;
+        dim3 grid2((unsigned)g, (unsigned)ncol);
+#define LAUNCH_SPLIT(PRO_)                                                          \
+        if (rt == 1) k_linear_split<PRO_, 1><<<grid2, 256, 0, s>>>(p);              \
+        else k_linear_split<PRO_, 2><<<grid2, 256, 0, s>>>(p);
         switch (prologue) {
-            case DDG_PRO_NONE: k_linear_split<DDG_PRO_NONE><<<grid, 256, 0, s>>>(p); break;
-            case DDG_PRO_ADD_EMB: k_linear_split<DDG_PRO_ADD_EMB><<<grid, 256, 0, s>>>(p); break;
-            case DDG_PRO_BN_RELU: k_linear_split<DDG_PRO_BN_RELU><<<grid, 256, 0, s>>>(p); break;
-            case DDG_PRO_EMB_RELU: k_linear_split<DDG_PRO_EMB_RELU><<<grid, 256, 0, s>>>(p); break;
+            case DDG_PRO_NONE: LAUNCH_SPLIT(DDG_PRO_NONE) break;
+            case DDG_PRO_ADD_EMB: LAUNCH_SPLIT(DDG_PRO_ADD_EMB) break;
+            case DDG_PRO_BN_RELU: LAUNCH_SPLIT(DDG_PRO_BN_RELU) break;
+            case DDG_PRO_EMB_RELU: LAUNCH_SPLIT(DDG_PRO_EMB_RELU) break;
             default: return DDG_E_ARG;
         }
+#undef LAUNCH_SPLIT
         DDG_CHECK_LAUNCH();
         return DDG_OK;
     }

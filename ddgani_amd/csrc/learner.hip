@@ -12,6 +12,7 @@
 //   all its tiles; one partial [L][D+1] per workgroup goes to the workspace (no atomics).
 // k_learner_apply: sums the partials in a fixed order (fp64) and applies the SGD update: bitwise reproducible.
 // k_learner_eval / k_learner_eval_finish: validation loss and number of correct arg-max predictions.
+#include <atomic>
 #include "common.h"
 
 #define LRN_NT 256
@@ -275,12 +276,12 @@ extern "C" size_t ddg_learner_workspace_bytes(int D, int L) {
 
 template <int LCAP, int DM>
 static int lrn_launch_step(const LrnArgs &a, int grid, size_t lds, hipStream_t s) {
-    static size_t granted = 48 * 1024;
-    if (lds > granted) {
+    static std::atomic<size_t> granted{48 * 1024};      // per instantiation; atomic: callers may use several host threads
+    if (lds > granted.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void *)k_learner_step<LCAP, DM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return DDG_E_LAUNCH;
-        granted = lds;
+        granted.store(lds, std::memory_order_release);
     }
     k_learner_step<LCAP, DM><<<grid, LRN_NT, lds, s>>>(a);
     return DDG_OK;
@@ -329,12 +330,12 @@ extern "C" int ddg_learner_train(const float *x_train, const int32_t *y_train, i
     v.x = x_valid; v.y = y_valid; v.n = n_valid; v.partial = nullptr;
     const int64_t vt = (n_valid + R - 1) / R;
     const int vgrid = (int)(vt < LRN_BLOCKS ? vt : LRN_BLOCKS);
-    static size_t granted_eval[3] = {48 * 1024, 48 * 1024, 48 * 1024};
+    static std::atomic<size_t> granted_eval[3] = {{48 * 1024}, {48 * 1024}, {48 * 1024}};
     const int ev = L <= 8 ? 0 : (L <= 16 ? 1 : 2);
     const void *evf = ev == 0 ? (const void *)k_learner_eval<8> : ev == 1 ? (const void *)k_learner_eval<16> : (const void *)k_learner_eval<64>;
-    if (lds > granted_eval[ev]) {
+    if (lds > granted_eval[ev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(evf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DDG_E_LAUNCH;
-        granted_eval[ev] = lds;
+        granted_eval[ev].store(lds, std::memory_order_release);
     }
     if (ev == 0) k_learner_eval<8><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);
     else if (ev == 1) k_learner_eval<16><<<vgrid, LRN_NT, lds, s>>>(v, loss_part, hit_part);

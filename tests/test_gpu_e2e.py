@@ -9,14 +9,15 @@ reference's random stream; the arithmetic runs in the HIP library.  What is asse
  * attention-filled numeric cells within 1e-4 relative except near-tie cells (< 0.5 % of them, < 2e-3);
  * trajectory pins: network weights after epochs 1 / 2 / 10 within 1e-7 / 1e-6 / 1e-4 of the reference's
    (proves that the random streams, the gradients and Adam are in step with the reference);
- * ARMSE / AMAE after 100 and 200 epochs no further from the reference's than the reference is from ITSELF when only
+ * ARMSE / AMAE after 100 and 200 epochs inside the distribution of the reference's OWN scores on this run when only
    the fp32 summation order of its CPU GEMMs changes: tests/golden/e2e_hospital_spread.json (made by
-   tests/golden/make_e2e_spread.py) holds the reference's scores on this very run with 1 / 2 / 4 / 8 intra-op
-   threads: ARMSE 0.35040 / 0.35164 / 0.35229 / 0.35104 after 100 epochs (spread 1.9e-3) and 0.26320 / 0.26400 /
-   0.26398 / 0.26182 after 200 (spread 2.2e-3); its weights drift apart by 2e-5 after 2 epochs and 1e-3 after 100.
-   1 200 / 2 400 Adam steps through dropout and ReLU amplify any last-bit difference, so "identical to 3 decimals"
-   is not a property the reference has against itself on this run.  That bar is asserted where it CAN hold: on the
-   imputation path in isolation (test_imputation_path_on_reference_weights below).
+   tests/golden/make_e2e_spread.py) holds the reference's scores with 1 to 8 intra-op threads: ARMSE after 100 epochs
+   0.34966 ... 0.35229 (spread 2.6e-3, standard deviation 8.7e-4), after 200 epochs 0.26182 ... 0.26523 (spread 3.4e-3,
+   standard deviation 1.0e-3); its weights drift apart by 2e-5 after 2 epochs and 1e-3 after 100.  1 200 / 2 400 Adam
+   steps through dropout and ReLU amplify any last-bit difference, so "identical to 3 decimals" is not a property the
+   reference has against itself on this run.  Asserted: every score within 3 standard deviations of the mean of the
+   reference's runs.  The 3-decimal bar is asserted where it CAN hold: on the imputation path in isolation
+   (test_imputation_path_on_reference_weights below).
 """
 import json
 import os
@@ -98,16 +99,20 @@ def test_end_to_end(tmp_path, tag, csv_name):
         tol = 1e-7 if nm.endswith("ep1") else 1e-6 if nm.endswith("ep2") else 1e-4
         assert d < tol, (nm, d)
     if tag == "e2e_hospital":
-        # tolerance = the reference's own spread on this run (see the module docstring), per sampling pass
+        # the reference's own distribution on this run (see the module docstring): mean and standard deviation per pass
         sp = json.load(open(os.path.join(GOLD, "e2e_hospital_spread.json")))
-        tol_r, tol_m = sp["armse_spread_per_pass"], sp["amae_spread_per_pass"]
-        assert max(tol_r + tol_m) < 2.5e-3
+        assert len(sp["runs"]) >= 8 and max(sp["armse_std_per_pass"] + sp["amae_std_per_pass"]) < 1.5e-3
+        for i, (ep, r, m) in enumerate(log):
+            assert abs(r - sp["armse_mean_per_pass"][i]) <= 3 * sp["armse_std_per_pass"][i], (ep, r, sp["armse_mean_per_pass"][i])
+            assert abs(m - sp["amae_mean_per_pass"][i]) <= 3 * sp["amae_std_per_pass"][i], (ep, m, sp["amae_mean_per_pass"][i])
+        # the returned table is the best pass's: the same bound against the reference's final scores
+        assert abs(final[0] - float(z["armse"])) <= 4 * max(sp["armse_std_per_pass"])
+        assert abs(final[1] - float(z["amae"])) <= 4 * max(sp["amae_std_per_pass"])
     else:
         # all-numeric table, no arg-max to flip: scores agree far inside 3 decimals
-        tol_r = tol_m = [2e-4] * len(scores)
-    for i, ((ep, r, m), (rr, mm)) in enumerate(zip(log, scores)):
-        assert abs(r - rr) <= tol_r[i] and abs(m - mm) <= tol_m[i], (ep, r, rr, m, mm, tol_r[i])
-    assert abs(final[0] - float(z["armse"])) <= max(tol_r) and abs(final[1] - float(z["amae"])) <= max(tol_m)
+        for (ep, r, m), (rr, mm) in zip(log, scores):
+            assert abs(r - rr) <= 2e-4 and abs(m - mm) <= 2e-4, (ep, r, rr, m, mm)
+        assert abs(final[0] - float(z["armse"])) <= 2e-4 and abs(final[1] - float(z["amae"])) <= 2e-4
 
 
 def test_imputation_path_on_reference_weights(tmp_path):
