@@ -69,6 +69,9 @@ SIGNATURES = {
                                     c_f32p, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "ddg_reverse_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float), C.c_int, C.c_int,
                                    C.c_uint64, C.c_uint64, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    "ddg_head_reverse_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.POINTER(C.c_float), C.c_int, C.c_int,
+                                        C.c_uint64, C.c_uint64, c_i32p, c_u8p, C.c_int, c_f32p, C.c_int64, C.c_int,
+                                        C.c_void_p]),
     "ddg_head": (C.c_int, [c_f32p, c_i32p, c_u8p, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "ddg_mask_merge": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_u8p, C.c_int, c_f32p, C.c_int64, C.c_int,
                                  C.c_void_p]),

@@ -179,21 +179,17 @@ __global__ void k_reverse_step(const float *__restrict__ xt, const float *__rest
     }
 }
 
+static int rev_coef(const float *sh, int T, int t, RevCoef &k);
+static inline int rev_coef_of(const float *sh, int T, int t, RevCoef &k) { return rev_coef(sh, T, t, k); }
+
 extern "C" int ddg_reverse_step(const float *x_t, const float *x, const float *M, const float *pred, const float *z,
                                 const float *sh, int T, int t, uint64_t seed, uint64_t stream_id, float *out,
                                 int64_t rows, int D, void *stream) {
     if (!x_t || !x || !M || !pred || !sh || !out || rows < 0 || D < 1) return DDG_E_ARG;
-    if (t < 2 || t > T) return DDG_E_ARG;
-    if (rows == 0) return DDG_OK;
-    const float *betas = sh, *sa = sh + 2 * T, *ac = sh + 5 * T, *sac = sh + 6 * T, *s1mac = sh + 7 * T;
-    // coefficient products in the reference's fp32 association (model/Diffusion.py:415-421)
     RevCoef k;
-    volatile float one_m_acm1 = 1.f - ac[t - 2];
-    volatile float c1 = sac[t - 2] * betas[t - 1];
-    volatile float c2 = sa[t - 1] * one_m_acm1;
-    volatile float c3 = one_m_acm1 * betas[t - 1];
-    volatile float den = 1.f - ac[t - 1];
-    k.c1 = c1; k.c2 = c2; k.c3 = c3; k.den = den; k.sacm1 = sac[t - 2]; k.s1mm1 = s1mac[t - 2];
+    int rc = rev_coef_of(sh, T, t, k);
+    if (rc) return rc;
+    if (rows == 0) return DDG_OK;
     const int64_t n = rows * D;
     k_reverse_step<<<ew_grid((n + 3) / 4, 256), 256, 0, (hipStream_t)stream>>>(x_t, x, M, pred, z, k, seed, stream_id, out, n);
     DDG_CHECK_LAUNCH();
@@ -242,6 +238,105 @@ __global__ void k_head_merge(const float *__restrict__ y, const float *__restric
         for (int i = threadIdx.x; i < nel; i += blockDim.x) out[base + i] = tile[i];
         __syncthreads();
     }
+}
+
+// a6 head + a7 reverse step in ONE pass: the denoiser's pre-head logits y go through the per-field head inside the LDS
+// tile and straight into the reverse-step formula; the prediction never travels to HBM and back (saves a write and a
+// read of [rows, D] per reverse step).  Same arithmetic as k_head_merge<false> followed by k_reverse_step, so the
+// results are bit-identical to the two-kernel sequence.  Noise: explicit z, or Philox indexed by the GLOBAL element
+// (group e >> 2, lane e & 3) exactly as k_reverse_step does.
+__global__ void k_head_reverse(const float *__restrict__ y, const float *__restrict__ xt, const float *__restrict__ x,
+                               const float *__restrict__ M, const float *__restrict__ z, RevCoef k, uint64_t seed,
+                               uint64_t stream_id, const int32_t *__restrict__ offsets,
+                               const uint8_t *__restrict__ is_cat, int C, float *__restrict__ out, int64_t rows, int D,
+                               int rows_pb) {
+    extern __shared__ float tile[];
+    const int64_t nblk = ceil_div64(rows, rows_pb);
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t r0 = blk * rows_pb;
+        const int nr = (int)((rows - r0 < rows_pb) ? rows - r0 : rows_pb);
+        const int64_t base = r0 * D;
+        const int nel = nr * D;
+        for (int i = threadIdx.x; i < nel; i += blockDim.x) tile[i] = y[base + i];
+        __syncthreads();
+        for (int w = threadIdx.x; w < nr * C; w += blockDim.x) {
+            const int r = w / C, f = w - r * C;
+            const int a = offsets[f], b = offsets[f + 1];
+            float *p = tile + r * D;
+            if (is_cat[f]) {
+                float mx = p[a];
+                for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
+                float s = 0.f;
+                for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
+                for (int j = a; j < b; ++j) p[j] = p[j] / s;
+            } else {
+                for (int j = a; j < b; ++j) p[j] = 1.f / (1.f + expf(-p[j]));
+            }
+        }
+        __syncthreads();
+        if ((base & 3) == 0) {
+            const int ng = (nel + 3) / 4;
+            for (int g = threadIdx.x; g < ng; g += blockDim.x) {
+                const int i0 = g * 4;
+                const int64_t e0 = base + i0;
+                if (i0 + 3 < nel) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(xt + e0);
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(x + e0);
+                    const f32x4 m = *reinterpret_cast<const f32x4 *>(M + e0);
+                    const f32x4 zz = z ? *reinterpret_cast<const f32x4 *>(z + e0) : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
+                    f32x4 r;
+                    r.x = rev_one(a.x, b.x, m.x, tile[i0], zz.x, k); r.y = rev_one(a.y, b.y, m.y, tile[i0 + 1], zz.y, k);
+                    r.z = rev_one(a.z, b.z, m.z, tile[i0 + 2], zz.z, k); r.w = rev_one(a.w, b.w, m.w, tile[i0 + 3], zz.w, k);
+                    *reinterpret_cast<f32x4 *>(out + e0) = r;
+                } else {
+                    const f32x4 z4 = z ? f32x4{0, 0, 0, 0} : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
+                    for (int c = 0; c < 4 && i0 + c < nel; ++c)
+                        out[e0 + c] = rev_one(xt[e0 + c], x[e0 + c], M[e0 + c], tile[i0 + c], z ? z[e0 + c] : z4[c], k);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+                const int64_t e = base + i;
+                const float zz = z ? z[e] : philox_normal4(seed, stream_id, (uint64_t)(e >> 2))[e & 3];
+                out[e] = rev_one(xt[e], x[e], M[e], tile[i], zz, k);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int rev_coef(const float *sh, int T, int t, RevCoef &k) {
+    if (t < 2 || t > T) return DDG_E_ARG;
+    const float *betas = sh, *sa = sh + 2 * T, *ac = sh + 5 * T, *sac = sh + 6 * T, *s1mac = sh + 7 * T;
+    // coefficient products in the reference's fp32 association (model/Diffusion.py:415-421)
+    volatile float one_m_acm1 = 1.f - ac[t - 2];
+    volatile float c1 = sac[t - 2] * betas[t - 1];
+    volatile float c2 = sa[t - 1] * one_m_acm1;
+    volatile float c3 = one_m_acm1 * betas[t - 1];
+    volatile float den = 1.f - ac[t - 1];
+    k.c1 = c1; k.c2 = c2; k.c3 = c3; k.den = den; k.sacm1 = sac[t - 2]; k.s1mm1 = s1mac[t - 2];
+    return DDG_OK;
+}
+
+extern "C" int ddg_head_reverse_step(const float *y, const float *x_t, const float *x, const float *M, const float *z,
+                                     const float *sh, int T, int t, uint64_t seed, uint64_t stream_id,
+                                     const int32_t *offsets, const uint8_t *is_cat, int C, float *out, int64_t rows,
+                                     int D, void *stream) {
+    if (!y || !x_t || !x || !M || !sh || !offsets || !is_cat || !out || rows < 0 || D < 1 || C < 1) return DDG_E_ARG;
+    RevCoef k;
+    int rc = rev_coef(sh, T, t, k);
+    if (rc) return rc;
+    if (rows == 0) return DDG_OK;
+    int rows_pb = 8192 / D;
+    if (rows_pb < 1) return DDG_E_UNSUPPORTED;
+    if (rows_pb > 64) rows_pb = 64;
+    const size_t lds = (size_t)rows_pb * D * sizeof(float);
+    const int64_t nblk = ceil_div64(rows, rows_pb);
+    const int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    k_head_reverse<<<grid, 256, lds, (hipStream_t)stream>>>(y, x_t, x, M, z, k, seed, stream_id, offsets, is_cat, C, out,
+                                                            rows, D, rows_pb);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
 }
 
 static int launch_head_merge(bool merge, const float *y, const float *x, const float *M, const int32_t *offsets,

@@ -175,11 +175,12 @@ def reverse_sample(P: GenParams, T: int, x: torch.Tensor, M: torch.Tensor, layou
     pred = torch.empty_like(x)
     i = 0
     for ts in range(T, 1, -1):
+        # t > 2: the head is fused into the reverse step (pre-head logits -> x_{t-1} in one pass); t = 2: x0_hat = head(y)
         ops.denoiser_fwd(P, x_t, ts, layout, drops=None if r is None else r.drops[i], drop_p=drop_p,
-                         seed=drop_seed(seed), stream_id=stream_of(call, KIND_DROP, ts), out=pred)
+                         seed=drop_seed(seed), stream_id=stream_of(call, KIND_DROP, ts), out=pred, apply_head=ts == 2)
         if ts > 2:
-            ops.reverse_step(x_t, x, M, pred, ts, T, z=None if r is None else r.zs[i], seed=seed,
-                             stream_id=stream_of(call, KIND_Z, ts), out=x_t, sched_host=sh)
+            ops.head_reverse_step(pred, x_t, x, M, ts, T, layout, z=None if r is None else r.zs[i], seed=seed,
+                                  stream_id=stream_of(call, KIND_Z, ts), out=x_t, sched_host=sh)
         i += 1
     return pred
 

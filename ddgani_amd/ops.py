@@ -108,6 +108,21 @@ def reverse_step(x_t, x, M, pred, t: int, T: int, z=None, seed: int = 0, stream_
     return out
 
 
+def head_reverse_step(y, x_t, x, M, t: int, T: int, layout: "FieldLayout", z=None, seed: int = 0, stream_id: int = 0,
+                      out=None, sched_host: Optional[np.ndarray] = None):
+    """ddg_head_reverse_step: reverse step from the generator's pre-head logits ``y`` (head fused in)."""
+    rows, D = x.shape
+    off, cat = layout.on(x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    sh = schedule(T) if sched_host is None else sched_host
+    check(lib().ddg_head_reverse_step(_ptr(y, torch.float32), _ptr(x_t, torch.float32), _ptr(x, torch.float32),
+                                      _ptr(M, torch.float32), _ptr(z, torch.float32),
+                                      sh.ctypes.data_as(C.POINTER(C.c_float)), T, int(t), seed, stream_id, _ptr(off),
+                                      _ptr(cat), layout.C, _ptr(out), rows, D, _stream()), "ddg_head_reverse_step")
+    return out
+
+
 # --------------------------------------------------------------------------- a6 head / a9
 def head(y, layout: FieldLayout, out=None):
     rows, D = y.shape

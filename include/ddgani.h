@@ -80,6 +80,15 @@ int ddg_reverse_step(const float *x_t, const float *x, const float *M, const flo
                      uint64_t seed, uint64_t stream_id, float *out, int64_t rows, int D,
                      void *stream);
 
+/* a6 (head) + a7 fused: G_D_onestep from the generator's PRE-HEAD logits y   model/Diffusion.py:188-201, :415-424
+ * out = reverse step of head(y): the per-field sigmoid / softmax and the posterior / re-noising / mask-merge formula in
+ * one HBM pass (the prediction is never written).  Bit-identical to ddg_head followed by ddg_reverse_step.
+ * offsets / is_cat: DEVICE arrays of the field layout.  In-place (out == x_t) is allowed. */
+int ddg_head_reverse_step(const float *y, const float *x_t, const float *x, const float *M, const float *z,
+                          const float *sched_host, int T, int t, uint64_t seed, uint64_t stream_id,
+                          const int32_t *offsets, const uint8_t *is_cat, int C, float *out, int64_t rows, int D,
+                          void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * a6 (head)  per-field sigmoid / softmax   model/Diffusion.py:188-201
  * a9  mask-merge + categorical re-softmax  model/Diffusion.py:598, :606-615

@@ -216,7 +216,7 @@ MODES = [pytest.param(0, id="f32"), pytest.param(1, id="bf16filter")]
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600"])
+@pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600", "attn_adult2000"])
 def test_attn_fill_golden(dev, name, mode):
     """fractional-k fixtures from the reference's init_attn_2 (k = int(N*top_k))."""
     z = load(name)

@@ -104,3 +104,29 @@ def test_default_calls_draw_fresh_noise():
     r1 = D_.reverse_sample(G.device_params(), T, x, M, G.layout, seed=5, call=77)
     r2 = D_.reverse_sample(G.device_params(), T, x, M, G.layout, seed=5, call=77)
     assert torch.equal(r1, r2)
+
+
+@pytest.mark.parametrize("widths", [[1, 1, 5, 1, 3, 1, 1, 8, 1], [1] * 177, [4] * 36 + [1] * 5])
+def test_fused_head_reverse_step_is_bit_identical(widths):
+    """ddg_head_reverse_step == ddg_head followed by ddg_reverse_step, bit for bit, with explicit noise and with the
+    on-chip generator (the Philox index is the global element, whatever the tiling); D = 177 gives tiles whose first
+    element is not a multiple of 4 (the scalar path)."""
+    from ddgani_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(len(widths))
+    lay = ops.FieldLayout(widths, dev)
+    N, D, T = 5003, lay.D, 6
+    y = (torch.randn(N, D, generator=g) * 2).to(dev)
+    x_t, x = torch.randn(N, D, generator=g).to(dev), torch.rand(N, D, generator=g).to(dev)
+    M = (torch.rand(N, D, generator=g) < 0.7).float().to(dev)
+    z = torch.randn(N, D, generator=g).to(dev)
+    for t in (T, 3):
+        pred = ops.head(y, lay)
+        for kw in (dict(z=z), dict(seed=5, stream_id=77)):
+            want = ops.reverse_step(x_t, x, M, pred, t, T, **kw)
+            got = ops.head_reverse_step(y, x_t, x, M, t, T, lay, **kw)
+            assert torch.equal(want, got), (t, list(kw))
+    # in place
+    xt2 = x_t.clone()
+    ops.head_reverse_step(y, xt2, x, M, T, T, lay, z=z, out=xt2)
+    assert torch.equal(xt2, ops.reverse_step(x_t, x, M, ops.head(y, lay), T, T, z=z))

@@ -16,7 +16,7 @@ def test_schedule(T):
         assert np.array_equal(v.numpy(), z[f"T{T}_{k}"]), k
 
 
-@pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600"])
+@pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600", "attn_adult2000"])
 def test_attn_dense_bit_exact(name):
     z = load(name)
     out = orc.attn_fill_dense(torch.tensor(z["X"]), torch.tensor(z["W"]), z["data_m"], z["offsets"].tolist(),
@@ -24,7 +24,7 @@ def test_attn_dense_bit_exact(name):
     assert np.array_equal(out, z["new_code"])
 
 
-@pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600"])
+@pytest.mark.parametrize("name", ["attn_num64", "attn_mixed257", "attn_onehot200", "attn_num600", "attn_adult2000"])
 def test_attn_closed_form_near_tie_aware(name):
     """closed form == reference except on cells flagged as near-ties (another logit within 1e-6 of
     the k-th), where a membership flip may move the value by up to ~1/k of the key spread."""
