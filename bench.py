@@ -98,6 +98,43 @@ def cpu_baseline(tab_cfg, lay_widths, k_frac_rows, T, D, N_full, sample_rows):
                       f"({t_samp:.1f} s = {Nsamp / t_samp:.0f} rows/s); torch CPU fp32, {cores} threads"}
 
 
+def other_rooflines(ops, P, xd, Md, lay, T, sched_host, reps=5):
+    """The two other kernel classes of the hot path, timed live with HIP events on the launch stream AFTER the timed
+    region (they are inside `value` already, as part of the sampler phase): the denoiser's dense layers (MFMA-bound)
+    and the fused head + reverse step (HBM-bound), each against its roofline."""
+    rows, D = xd.shape
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    pre = torch.empty_like(xd)
+    x_t = xd.clone()
+    ops.denoiser_fwd(P, x_t, 3, lay, seed=1, stream_id=1, out=pre, apply_head=False)
+    e0, e1, e2 = ev(), ev(), ev()
+    e0.record()
+    for i in range(reps):
+        ops.denoiser_fwd(P, x_t, 3, lay, seed=1, stream_id=2 + i, out=pre, apply_head=False)
+    e1.record()
+    for i in range(reps):
+        ops.head_reverse_step(pre, x_t, xd, Md, 3, T, lay, seed=1, stream_id=50 + i, out=x_t, sched_host=sched_host)
+    e2.record()
+    torch.cuda.synchronize()
+    t_gemm = e0.elapsed_time(e1) / reps * 1e-3            # one denoiser call = 4 dense layers (+ 3 BatchNorm finalizes)
+    t_ew = e1.elapsed_time(e2) / reps * 1e-3
+    flops = 16.0 * D * D * rows                           # SURVEY 8(d): 16 D^2 flop per row and denoiser call
+    split = rows >= 8192
+    byts = 5.0 * 4.0 * rows * D                           # y, x_t, x, M in; x_{t-1} out (noise on chip)
+    return {
+        "gemm": {"kernel": "k_linear_split (4 dense layers of one denoiser call; f16 MFMA on operands split in two halves, "
+                           "fp32-class)" if split else "k_linear (fp32 MFMA)",
+                 "bound": "mfma", "achieved": flops / t_gemm / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": flops / t_gemm / 1e12 / PEAK_F32_MFMA_TFLOPS, "launch_ms": t_gemm * 1e3,
+                 "note": "algorithmic fp32 flops against the fp32-matrix peak; the split kernel executes 3 f16 products per "
+                         "multiply-add: executed rate %.0f TFLOP/s = %.3f of the 2500 TFLOP/s dense f16 peak"
+                         % (3 * flops / t_gemm / 1e12, 3 * flops / t_gemm / 1e12 / PEAK_BF16_MFMA_TFLOPS)},
+        "elementwise": {"kernel": "k_head_reverse (per-field head + reverse step, one pass)", "bound": "hbm",
+                        "achieved": byts / t_ew / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / t_ew / 1e9 / 8000.0,
+                        "launch_ms": t_ew * 1e3, "bytes_per_launch": byts},
+    }
+
+
 def pmc_traffic(workload, rows, kernel_prefix):
     """HBM bytes per step (summed over the kernel's launches of one step, like `achieved`) of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/rNN/pmc_traffic_<workload>_rows<N>.json: FETCH_SIZE and WRITE_SIZE collected in separate
@@ -276,6 +313,8 @@ def main():
                                            "timed together with HIP events on the launch stream; flops count only the "
                                            "2*D*pairs*keys of the similarity") if filt else "one launch per step"},
         }
+        if world == 1:
+            res["roofline_other_kernels"] = other_rooflines(ops, P, xd, Md, lay, T, sched_host)
         if not a.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lay.widths, k, T, lay.D, N, a.cpu_rows)
         else:

@@ -257,7 +257,14 @@ __global__ void k_head_reverse(const float *__restrict__ y, const float *__restr
         const int nr = (int)((rows - r0 < rows_pb) ? rows - r0 : rows_pb);
         const int64_t base = r0 * D;
         const int nel = nr * D;
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) tile[i] = y[base + i];
+        if ((base & 3) == 0) {
+            const int n4 = nel >> 2;
+            for (int i = threadIdx.x; i < n4; i += blockDim.x)
+                *reinterpret_cast<f32x4 *>(tile + 4 * i) = *reinterpret_cast<const f32x4 *>(y + base + 4 * i);
+            for (int i = 4 * n4 + threadIdx.x; i < nel; i += blockDim.x) tile[i] = y[base + i];
+        } else {
+            for (int i = threadIdx.x; i < nel; i += blockDim.x) tile[i] = y[base + i];
+        }
         __syncthreads();
         for (int w = threadIdx.x; w < nr * C; w += blockDim.x) {
             const int r = w / C, f = w - r * C;

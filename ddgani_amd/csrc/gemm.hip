@@ -271,25 +271,31 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4 &hi, f16x4 &lo) {
 // hi and the cross sums together), which lets four workgroups share a CU: the layer is bound by the latency of the
 // operand loads (K is only 176 / 352 deep, a chunk's MFMAs last ~0.35 us), so more waves in flight is what pays.
 // One LDS buffer; the next chunk's global loads are in flight in registers while the current chunk is multiplied.
-template <int PRO, int RT>
+template <int PRO, int RT, int KCH>
 __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs p) {
     constexpr int BMS = 64 * RT;
-    __shared__ __attribute__((aligned(16))) char As[BMS * SPLIT_STRIDE];
-    __shared__ __attribute__((aligned(16))) char Bs[BN * SPLIT_STRIDE];
-    __shared__ double red[4][2][2][32];
+    constexpr int SSTR = 4 * KCH + 16;          // bytes per LDS row: KCH hi halves | KCH lo halves | pad
+    constexpr int C4 = KCH / 4;                 // float4 per row and chunk
+    constexpr int RPP = 256 / C4;               // rows staged per pass of the workgroup
+    constexpr int NPA = BMS / RPP, NPB = BN / RPP;
+    // one LDS block: A tile | B tile; the fp64 column partials of the last phase reuse the A tile
+    __shared__ __attribute__((aligned(16))) char lds_[(BMS + BN) * SSTR];
+    char *As = lds_, *Bs = lds_ + BMS * SSTR;
+    static_assert(BMS * SSTR >= 4 * 2 * 2 * 32 * 8, "A tile holds the statistics partials");
+    double(*red)[2][2][32] = reinterpret_cast<double(*)[2][2][32]>(lds_);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int r32 = lane & 31, h = lane >> 5;
     const int col0 = blockIdx.y * BN;
-    const int nchunks = (p.in + BK - 1) / BK;
+    const int nchunks = (p.in + KCH - 1) / KCH;
     const int64_t ntiles = ceil_div64(p.rows, BMS);
     const float keep_scale = 1.f / (1.f - p.drop_p);
     const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
 
     double s1[2] = {0, 0}, s2[2] = {0, 0};
-    const int st_c4 = tid & 7, st_r = tid >> 3;
+    const int st_c4 = tid % C4, st_r = tid / C4;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * BMS;
@@ -301,39 +307,39 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { accH[a][b][g] = 0.f; accX[a][b][g] = 0.f; }
 
-        int trows[2 * RT];
+        int trows[NPA];
 #pragma unroll
-        for (int i = 0; i < 2 * RT; ++i) {
-            const int64_t row = row0 + st_r + 32 * i;
+        for (int i = 0; i < NPA; ++i) {
+            const int64_t row = row0 + st_r + RPP * i;
             trows[i] = 0;
             if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
                 trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
         }
 
-        f32x4 pa[2 * RT], pb[4];
+        f32x4 pa[NPA], pb[NPB];
         auto fetch = [&](int chunk) {
-            const int k0 = chunk * BK + st_c4 * 4;
+            const int k0 = chunk * KCH + st_c4 * 4;
 #pragma unroll
-            for (int i = 0; i < 2 * RT; ++i)
-                pa[i] = lin_stage_a<PRO>(p, row0 + st_r + 32 * i, k0, trows[i], keep_scale, fast);
+            for (int i = 0; i < NPA; ++i)
+                pa[i] = lin_stage_a<PRO>(p, row0 + st_r + RPP * i, k0, trows[i], keep_scale, fast);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pb[i] = lin_stage_b(p, col0 + st_r + 32 * i, k0, fast);
+            for (int i = 0; i < NPB; ++i) pb[i] = lin_stage_b(p, col0 + st_r + RPP * i, k0, fast);
         };
         auto commit = [&]() {
             f16x4 hi, lo;
 #pragma unroll
-            for (int i = 0; i < 2 * RT; ++i) {
-                const int rl = st_r + 32 * i;
+            for (int i = 0; i < NPA; ++i) {
+                const int rl = st_r + RPP * i;
                 split4(pa[i], hi, lo);
-                *reinterpret_cast<f16x4 *>(&As[rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
-                *reinterpret_cast<f16x4 *>(&As[rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
+                *reinterpret_cast<f16x4 *>(&As[rl * SSTR + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&As[rl * SSTR + 2 * KCH + st_c4 * 8]) = lo;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rl = st_r + 32 * i;
+            for (int i = 0; i < NPB; ++i) {
+                const int rl = st_r + RPP * i;
                 split4(pb[i], hi, lo);
-                *reinterpret_cast<f16x4 *>(&Bs[rl * SPLIT_STRIDE + st_c4 * 8]) = hi;
-                *reinterpret_cast<f16x4 *>(&Bs[rl * SPLIT_STRIDE + 64 + st_c4 * 8]) = lo;
+                *reinterpret_cast<f16x4 *>(&Bs[rl * SSTR + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&Bs[rl * SSTR + 2 * KCH + st_c4 * 8]) = lo;
             }
         };
 
@@ -344,20 +350,20 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
             if (c + 1 < nchunks) fetch(c + 1);     // in flight while this chunk is multiplied
             __syncthreads();
             // fragment of k-step u (16 deep): lane half h holds k = 16u + 8h .. + 7 of its row: one 16-byte read
-            const char *Ab = &As[(wr * 32 * RT + r32) * SPLIT_STRIDE + 16 * h];
-            const char *Bb = &Bs[(wc * 64 + r32) * SPLIT_STRIDE + 16 * h];
+            const char *Ab = &As[(wr * 32 * RT + r32) * SSTR + 16 * h];
+            const char *Bb = &Bs[(wc * 64 + r32) * SSTR + 16 * h];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < KCH / 16; ++u) {
                 f16x8 ah[RT], al[RT], bh[2], bl[2];
 #pragma unroll
                 for (int q = 0; q < RT; ++q) {
-                    ah[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SPLIT_STRIDE + 32 * u);
-                    al[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SPLIT_STRIDE + 64 + 32 * u);
+                    ah[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SSTR + 32 * u);
+                    al[q] = *reinterpret_cast<const f16x8 *>(Ab + q * 32 * SSTR + 2 * KCH + 32 * u);
                 }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    bh[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SPLIT_STRIDE + 32 * u);
-                    bl[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SPLIT_STRIDE + 64 + 32 * u);
+                    bh[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SSTR + 32 * u);
+                    bl[q] = *reinterpret_cast<const f16x8 *>(Bb + q * 32 * SSTR + 2 * KCH + 32 * u);
                 }
 #pragma unroll
                 for (int ra = 0; ra < RT; ++ra)
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
             }
         }
     }
+    __syncthreads();                               // the last tile's fragment reads are done: the A tile becomes `red`
     LIN_STATS()
 }
 
@@ -414,6 +421,9 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
     dim3 grid((unsigned)gx, (unsigned)ncol);
     if (p.rows >= SPLIT_MIN_ROWS && !linear_force_f32()) {
         static const int rt = [] { const char *e = getenv("DDG_SPLIT_RT"); return (e && e[0] == '2') ? 2 : 1; }();
+        // chunk depth: 32 (default); DDG_SPLIT_KCH=64 selects 64-deep chunks, measured SLOWER (sampler 65.9 vs 41.9 ms
+        // at 1M x 176: the doubled prefetch registers spill ~100 VGPRs at three workgroups per CU)
+        static const int kch = [] { const char *e = getenv("DDG_SPLIT_KCH"); return (e && e[0] == '6') ? 64 : 32; }();
         const int64_t nt = ceil_div64(p.rows, 64 * rt);
         int64_t g = nt;
         const int64_t cap2 = (256 * (rt == 1 ? 3 : 2) + ncol - 1) / ncol;
@@ -421,8 +431,9 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
         if (g >= 8) g -= g % 8;
         dim3 grid2((unsigned)g, (unsigned)ncol);
 #define LAUNCH_SPLIT(PRO_)                                                          \
-        if (rt == 1) k_linear_split<PRO_, 1><<<grid2, 256, 0, s>>>(p);              \
-        else k_linear_split<PRO_, 2><<<grid2, 256, 0, s>>>(p);
+        if (rt == 1 && kch == 64) k_linear_split<PRO_, 1, 64><<<grid2, 256, 0, s>>>(p);   \
+        else if (rt == 1) k_linear_split<PRO_, 1, 32><<<grid2, 256, 0, s>>>(p);     \
+        else k_linear_split<PRO_, 2, 32><<<grid2, 256, 0, s>>>(p);
         switch (prologue) {
             case DDG_PRO_NONE: LAUNCH_SPLIT(DDG_PRO_NONE) break;
             case DDG_PRO_ADD_EMB: LAUNCH_SPLIT(DDG_PRO_ADD_EMB) break;
