@@ -271,7 +271,10 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4 &hi, f16x4 &lo) {
 // hi and the cross sums together), which lets four workgroups share a CU: the layer is bound by the latency of the
 // operand loads (K is only 176 / 352 deep, a chunk's MFMAs last ~0.35 us), so more waves in flight is what pays.
 // One LDS buffer; the next chunk's global loads are in flight in registers while the current chunk is multiplied.
-template <int PRO, int RT, int KCH>
+// Measured and NOT kept (sampler pass at 1M x 176, ms): four workgroups per CU 49.5 (spills), 64-deep chunks 65.9
+// (spills), the A operand fetched two chunks ahead 39.6 (no change), output tiles transposed through LDS for 16-byte
+// stores 42.9; kept: 39.6.
+template <int PRO, int RT, int KCH, bool FAST>
 __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs p) {
     constexpr int BMS = 64 * RT;
     constexpr int SSTR = 4 * KCH + 16;          // bytes per LDS row: KCH hi halves | KCH lo halves | pad
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
     const int nchunks = (p.in + KCH - 1) / KCH;
     const int64_t ntiles = ceil_div64(p.rows, BMS);
     const float keep_scale = 1.f / (1.f - p.drop_p);
-    const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
+    constexpr bool fast = FAST;          // FAST: no concatenated operand and in % 4 == 0 (16-byte operand loads); a compile-time
+                                         // flag: with both paths alive the kernel spilled 26-49 registers (sampler 41.9 -> 39.6 ms)
 
     double s1[2] = {0, 0}, s2[2] = {0, 0};
     const int st_c4 = tid % C4, st_r = tid / C4;
@@ -430,10 +434,12 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
         if (g > cap2) g = cap2;
         if (g >= 8) g -= g % 8;
         dim3 grid2((unsigned)g, (unsigned)ncol);
+        const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
 #define LAUNCH_SPLIT(PRO_)                                                          \
-        if (rt == 1 && kch == 64) k_linear_split<PRO_, 1, 64><<<grid2, 256, 0, s>>>(p);   \
-        else if (rt == 1) k_linear_split<PRO_, 1, 32><<<grid2, 256, 0, s>>>(p);     \
-        else k_linear_split<PRO_, 2, 32><<<grid2, 256, 0, s>>>(p);
+        if (!fast) k_linear_split<PRO_, 1, 32, false><<<grid2, 256, 0, s>>>(p);     \
+        else if (rt == 1 && kch == 64) k_linear_split<PRO_, 1, 64, true><<<grid2, 256, 0, s>>>(p);   \
+        else if (rt == 1) k_linear_split<PRO_, 1, 32, true><<<grid2, 256, 0, s>>>(p);     \
+        else k_linear_split<PRO_, 2, 32, true><<<grid2, 256, 0, s>>>(p);
         switch (prologue) {
             case DDG_PRO_NONE: LAUNCH_SPLIT(DDG_PRO_NONE) break;
             case DDG_PRO_ADD_EMB: LAUNCH_SPLIT(DDG_PRO_ADD_EMB) break;
