@@ -34,8 +34,23 @@
 #define TK 32            // keys per tile
 #define HBINS 128
 #define HSTRIDE 129
+#define WHSTRIDE 131     // window passes: [0] below the bracket, [1 .. HBINS] its bins, [HBINS + 1] above
 
-enum { MODE_TOPK = 0, MODE_HIST = 1, MODE_FILL = 2 };
+enum { MODE_TOPK = 0, MODE_HIST = 1, MODE_FILL = 2, MODE_WIN = 3, MODE_WFILL = 4 };
+// Window selection for k > DDG_MAX_TOPK_REG (run_window_select / run_window_fill below): the k-th largest logit of
+// a pair is bracketed on a strided SAMPLE of its keys (three cheap passes), the bracket is resolved to one of 128
+// bins by ONE full pass that also counts what lies above it, and the second full pass accumulates everything
+// above that bin while listing the bin's own keys (<= WIN_CAP) for an exact in-list selection (k_attn_wlist).
+// Two full similarity passes instead of the radix path's six; pairs whose bracket misses go through the radix path.
+enum { WIN_MINMAX = 0, WIN_SHIST = 1, WIN_FULL = 2 };
+#define WIN_SAMPLE 8192      // sampled keys per column (stride = nk / WIN_SAMPLE)
+#define WIN_CAP 512          // listed keys per pair
+#define WIN_GROUP 4096       // workgroups per launch group of the second full pass (bounds the lists)
+#define WIN_SIGMAS 6.f       // half width of the sample bracket in standard deviations of the sample rank
+#define ATTN_WINDOW 100      // internal selector of run_select (not a public mode)
+#define WST_OPENTOP 1        // the bracket has no upper edge: logits above it count into bin 127
+#define WST_OPENBOT 2        // ... no lower edge: logits below it count into bin 0
+#define WST_ALL 4            // nk < k: every valid key is kept
 // The register path tracks the k+2 largest logits of a pair: the k kept ones, the (k+1)-th that decides
 // whether the k-th is tied, and the (k+2)-th that tells a two-way tie (both kept, resolved on the spot)
 // from a longer one (left to the threshold pass).
@@ -70,6 +85,15 @@ struct AttnArgs {
     int k;
     int level;                 // radix level (MODE_HIST)
     int dcs;                   // LDS accumulator stride (MODE_FILL)
+    // window selection (k > DDG_MAX_TOPK_REG)
+    float *wlo, *ww;           // [slots] lower edge and bin width of the pair's current bracket (128 bins)
+    int32_t *wst;              // [slots] WST_* bits | selected bin << 8
+    int32_t *nab;              // [slots] sample passes: sampled logits above the bracket; after MODE_WFILL: listed keys
+    float *zab;                // [slots] MODE_WFILL: sum of the weights above the selected bin
+    int32_t *lpos;             // [(block - blk_lo) * 128 + pair][wcap] key-list positions of the selected bin's keys
+    float *lval;               //   ... and their logits
+    int sample;                // 1: stream every (nk / WIN_SAMPLE)-th key only
+    int wcap;                  // list capacity in use (<= WIN_CAP; tests shrink it to force the radix fallback)
 };
 
 __device__ __forceinline__ uint32_t f2key(float v) {
@@ -201,28 +225,25 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     __shared__ int s_col;
 
     const int nblocks = p.qb_start[p.C];
-    if ((int)blockIdx.x >= nblocks) return;
+    const int blk = p.blk_lo + (int)blockIdx.x;
+    if (blk >= nblocks) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
 
-    if (tid == 0) {
-        int lo = 0, hi = p.C;      // largest c with qb_start[c] <= blockIdx.x
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (p.qb_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
-        }
-        s_col = lo;
-    }
+    if (tid == 0) s_col = block_column(p.qb_start, p.C, blk);
     __syncthreads();
     const int c = s_col;
-    const int nk = p.nk[c];
+    const int nk_all = p.nk[c];
+    // sample passes stream every kstride-th position of the key list
+    const int kstride = (MODE == MODE_WIN && p.sample && nk_all >= 2 * WIN_SAMPLE) ? nk_all / WIN_SAMPLE : 1;
+    const int nk = (nk_all + kstride - 1) / kstride;
     const int32_t *kl = p.klist + (int64_t)c * p.Nk;
     const int off_c = p.offsets[c];
     const int d_c = p.offsets[c + 1] - off_c;
 
-    const int64_t slot = ((int64_t)blockIdx.x * 4 + wid) * 32 + r32;
+    const int64_t slot = ((int64_t)blk * 4 + wid) * 32 + r32;
     const int qrow = p.qlist[slot];
 
     // ---- query operand in registers: breg[4u+s] = W[c][k] * x_q[k], k = 8u + 4h + s
@@ -271,13 +292,48 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         float *accb = extra + (int64_t)tid * p.dcs;
         for (int e = 0; e < d_c; ++e) accb[e] = 0.f;
     }
+    // window passes: tt = fma(v, winv, nwl) is the bin coordinate of a logit inside the pair's bracket (the same
+    // expression in both full passes, so a logit falls into the same bin in both)
+    float winv = 0.f, nwl = 0.f, smin = INFINITY, fb = INFINITY, fb1 = INFINITY;
+    float accr[8];
+    int wst = 0;
+    if (MODE == MODE_WIN) {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(extra);
+        for (int i = tid; i < QPB * WHSTRIDE; i += 256) hist[i] = 0;
+        if (p.level != WIN_MINMAX) {
+            winv = 1.f / p.ww[slot];
+            nwl = -p.wlo[slot] * winv;
+        }
+    }
+    if (MODE == MODE_WFILL) {
+        int *lcur = reinterpret_cast<int *>(extra);                 // [QPB] list cursors, then the accumulators
+        for (int i = tid; i < QPB; i += 256) lcur[i] = 0;
+        winv = 1.f / p.ww[slot];
+        nwl = -p.wlo[slot] * winv;
+        wst = p.wst[slot];
+        smax = p.smax[slot];
+        active = qrow >= 0 && p.flag[slot] == 0;
+        if (active) {
+            // selected bin b: logits with tt >= b + 1 lie above it, b <= tt < b + 1 inside.  A bracket without an upper
+            // (lower) edge counted everything above (below) it into bin 127 (0).  WST_ALL: nwl = +inf, all kept.
+            const int b = wst >> 8;
+            fb = ((wst & WST_OPENBOT) && b == 0) ? -INFINITY : (float)b;
+            fb1 = ((wst & WST_OPENTOP) && b == HBINS - 1) ? INFINITY : (float)(b + 1);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accr[e] = 0.f;
+        if (d_c > 8) {
+            float *accb = extra + QPB + (int64_t)tid * p.dcs;
+            for (int e = 0; e < d_c; ++e) accb[e] = 0.f;
+        }
+    }
 
     // ---- key streaming
     const int st_row = tid >> 3, st_c = tid & 7;
     f32x4 pf[NPF];
     auto prefetch = [&](int t) {
         const int pos = t * TK + st_row;
-        const int kidx = pos < nk ? kl[pos] : -1;
+        const int kidx = pos < nk ? kl[(int64_t)pos * kstride] : -1;
         const float *src = p.Xkp + (int64_t)(kidx < 0 ? 0 : kidx) * DP + st_c * 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -344,6 +400,69 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                     if (match) atomicAdd(&hist[(key >> sh) & bmask], 1u);
                 }
             }
+        } else if (MODE == MODE_WIN) {
+            // branch-free: every logit adds one to a counter of its query's row -- [0] below the bracket, [1 + bin],
+            // [1 + HBINS] above it (rows of the last tile past the key list count as "below": taken out at the end)
+            uint32_t *hist = reinterpret_cast<uint32_t *>(extra) + (wid * 32 + r32) * WHSTRIDE;
+            if (!full) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    if ((g & 3) + 8 * (g >> 2) + 4 * h >= rem) acc[g] = (p.level == WIN_MINMAX) ? NAN : -INFINITY;
+            }
+            if (p.level == WIN_MINMAX) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    smax = fmaxf(smax, acc[g]);       // fmaxf / fminf drop a NaN operand
+                    smin = fminf(smin, acc[g]);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float v = acc[g];
+                    if (p.level == WIN_FULL) smax = fmaxf(smax, v);
+                    int idx = (int)floorf(fmaf(v, winv, nwl));
+                    idx = min(max(idx, -1), HBINS) + 1;
+                    atomicAdd(&hist[idx], 1u);
+                }
+            }
+        } else if (MODE == MODE_WFILL) {
+            int *lcur = reinterpret_cast<int *>(extra);
+            if (!full) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    if ((g & 3) + 8 * (g >> 2) + 4 * h >= rem) acc[g] = -INFINITY;     // tt = -inf or NaN: neither kept nor listed
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                const float v = acc[g];
+                const float tt = fmaf(v, winv, nwl);
+                const bool keep = tt >= fb1;
+                const float w = keep ? __builtin_amdgcn_exp2f((v - smax) * 1.44269504088896340736f) : 0.f;
+                Z += w;
+                const float *xr = cur + kr * LSTR + off_c;
+                if (d_c == 1) {
+                    accr[0] += w * xr[0];
+                } else if (d_c <= 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) accr[e] += w * xr[e];      // e >= d_c: finite neighbours, never read back
+                } else {
+                    float *accb = extra + QPB + (int64_t)tid * p.dcs;
+                    if (__any(keep))
+                        for (int e = 0; e < d_c; ++e) accb[e] += w * xr[e];
+                }
+                const bool inb = tt >= fb && !keep;
+                if (__any(inb)) {
+                    if (inb) {                                              // inside the selected bin: listed for k_attn_wlist
+                        const int i = atomicAdd(&lcur[wid * 32 + r32], 1);
+                        if (i < p.wcap) {
+                            const int64_t o = (((int64_t)blockIdx.x * QPB) + wid * 32 + r32) * p.wcap + i;
+                            p.lpos[o] = t * TK + kr;
+                            p.lval[o] = v;
+                        }
+                    }
+                }
+            }
         } else {  // MODE_FILL
             float *accb = extra + (int64_t)tid * p.dcs;
 #pragma unroll
@@ -371,12 +490,109 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     // ---- per-mode finish
     if constexpr (MODE == MODE_TOPK) {
         topk_finish<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
+    } else if (MODE == MODE_WIN) {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(extra);
+        smax = fmaxf(smax, __shfl_xor(smax, 32));
+        smin = fminf(smin, __shfl_xor(smin, 32));
+        if (p.level == WIN_MINMAX) {
+            if (h == 0) {
+                // the whole sampled range as the first bracket; nk_all < k keeps every key (wlo = -inf puts them all above)
+                const bool all = nk_all < p.k;
+                p.wlo[slot] = all ? -INFINITY : smin;
+                p.ww[slot] = all ? 1.f : fmaxf((smax - smin) * (1.f / HBINS), 1e-30f);
+                p.wst[slot] = all ? WST_ALL : 0;
+                p.flag[slot] = 0;
+                p.rank[slot] = 0;
+            }
+        } else {
+            if (p.level == WIN_FULL && h == 0) p.smax[slot] = smax;
+            __syncthreads();   // all histogram atomics of the block are done
+            if (tid < QPB) {
+                const int64_t sl = (int64_t)blk * QPB + tid;
+                const uint32_t *hrow = hist + tid * WHSTRIDE;
+                const uint32_t *hq = hrow + 1;
+                const int st = p.wst[sl];
+                if (!(st & WST_ALL) && p.qlist[sl] >= 0) {
+                    const float lo = p.wlo[sl], w = p.ww[sl];
+                    const int below = (int)hrow[0] - (ntk * TK - nk), above = (int)hrow[1 + HBINS];
+                    if (p.level == WIN_SHIST) {
+                        // sample ranks that bracket the population's k-th largest with WIN_SIGMAS of slack
+                        const float q = (float)p.k / (float)nk_all;
+                        const float rs = q * (float)nk;
+                        const float gs = WIN_SIGMAS * sqrtf((float)nk * q * (1.f - q)) + 3.f;
+                        const int tgt_hi = (int)floorf(rs - gs);     // at most this many sampled logits above the bracket
+                        const int tgt_lo = (int)ceilf(rs + gs);      // at least this many at or above its lower edge
+                        int nst = st, ab = above, b_hi = HBINS - 1;
+                        if ((st & WST_OPENTOP) || tgt_hi < ab) {
+                            nst |= WST_OPENTOP;
+                        } else {
+                            while (b_hi > 0 && ab + (int)hq[b_hi] <= tgt_hi) ab += (int)hq[b_hi--];
+                        }
+                        int cum = (nst & WST_OPENTOP) ? above : ab, b_lo = b_hi;
+                        for (;; --b_lo) {
+                            cum += (int)hq[b_lo];
+                            if (cum >= tgt_lo || b_lo == 0) break;
+                        }
+                        if ((st & WST_OPENBOT) || cum < tgt_lo) nst |= WST_OPENBOT;
+                        p.wlo[sl] = lo + (float)b_lo * w;
+                        p.ww[sl] = fmaxf((float)(b_hi - b_lo + 1) * w * (1.f / HBINS), 1e-30f);
+                        p.wst[sl] = nst;
+                    } else {
+                        // the bin of the k-th largest logit and its rank inside the bin; a bracket without an upper
+                        // (lower) edge takes everything above (below) into its last (first) bin
+                        const int top_extra = (st & WST_OPENTOP) ? above : 0;
+                        const int bot_extra = (st & WST_OPENBOT) ? below : 0;
+                        const int r = p.k - ((st & WST_OPENTOP) ? 0 : above);
+                        int cum = 0, b = HBINS - 1, cnt = 0;
+                        bool found = false;
+                        if (r > 0) {
+                            for (; b >= 0; --b) {
+                                cnt = (int)hq[b] + (b == HBINS - 1 ? top_extra : 0) + (b == 0 ? bot_extra : 0);
+                                if (cum + cnt >= r) { found = true; break; }
+                                cum += cnt;
+                            }
+                        }
+                        if (found && cnt <= p.wcap) {
+                            p.wst[sl] = (st & 0xff) | (b << 8);
+                            p.rank[sl] = r - cum;
+                            p.flag[sl] = 0;
+                        } else {
+                            p.flag[sl] = 1;      // bracket missed, or too many keys in the bin: radix path
+                            p.rank[sl] = 0;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (MODE == MODE_WFILL) {
+        int *lcur = reinterpret_cast<int *>(extra);
+        const float Zt = Z + __shfl_xor(Z, 32);
+        // un-normalised sums of everything above the selected bin; k_attn_wlist adds the bin's kept keys and divides
+        if (d_c <= 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = accr[e] + __shfl_xor(accr[e], 32);
+                if (h == 0 && active && e < d_c) p.out_code[(int64_t)qrow * p.D + off_c + e] = a;
+            }
+        } else {
+            __syncthreads();
+            if (h == 0 && active) {
+                const float *a0 = extra + QPB + (int64_t)tid * p.dcs;
+                const float *a1 = extra + QPB + (int64_t)(tid + 32) * p.dcs;
+                for (int e = 0; e < d_c; ++e) p.out_code[(int64_t)qrow * p.D + off_c + e] = a0[e] + a1[e];
+            }
+        }
+        __syncthreads();
+        if (h == 0 && active) {
+            p.zab[slot] = Zt;
+            p.nab[slot] = lcur[wid * 32 + r32];
+        }
     } else if (MODE == MODE_HIST) {
         smax = fmaxf(smax, __shfl_xor(smax, 32));
         if (p.level == 0 && h == 0) p.smax[slot] = smax;
         __syncthreads();   // all histogram atomics of the block are done
         if (tid < QPB) {
-            const int64_t sl = (int64_t)blockIdx.x * QPB + tid;
+            const int64_t sl = (int64_t)blk * QPB + tid;
             const uint32_t *hq = reinterpret_cast<uint32_t *>(extra) + tid * HSTRIDE;
             int r = (p.level == 0) ? p.k : p.rank[sl];
             uint32_t pre = (p.level == 0) ? 0u : p.prefix[sl];
@@ -418,6 +634,86 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     }
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- window selection, last step: the keys MODE_WFILL listed for a pair (those of the bin that holds its k-th largest
+// logit, with their exact logits) are ranked against each other; tau is the rank-th largest of them (every key tied
+// with it is kept, utils/util.py:470-476), the kept ones join the sums MODE_WFILL left in out_code / zab, and the fill
+// is normalised.  One wave per pair at a time, 32 pairs per wave.
+__global__ __launch_bounds__(256) void k_attn_wlist(AttnArgs p) {
+    __shared__ float s_val[4][WIN_CAP];
+    __shared__ int s_pos[4][WIN_CAP];
+    const int nblocks = p.qb_start[p.C];
+    const int blk = p.blk_lo + (int)blockIdx.x;
+    if (blk >= nblocks) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = block_column(p.qb_start, p.C, blk);
+    const int32_t *kl = p.klist + (int64_t)c * p.Nk;
+    const int off_c = p.offsets[c];
+    const int d_c = p.offsets[c + 1] - off_c;
+    float *val = s_val[wid];
+    int *pos = s_pos[wid];
+    for (int pr = 0; pr < 32; ++pr) {
+        const int64_t slot = (int64_t)blk * QPB + wid * 32 + pr;
+        const int qrow = p.qlist[slot];
+        const bool on = qrow >= 0 && p.flag[slot] == 0;
+        const int n = on ? min(p.nab[slot], p.wcap) : 0;
+        const int r = on ? p.rank[slot] : 0;
+        const float smax = on ? p.smax[slot] : 0.f;
+        const int64_t lo = ((int64_t)blockIdx.x * QPB + wid * 32 + pr) * p.wcap;
+        __syncthreads();        // the previous pair's list is no longer read
+        for (int i = lane; i < n; i += 64) {
+            val[i] = p.lval[lo + i];
+            pos[i] = p.lpos[lo + i];
+        }
+        __syncthreads();
+        float tau = -INFINITY;
+        if (r > 0) {
+            for (int i = lane; i < n; i += 64) {
+                const float vi = val[i];
+                int gt = 0, ge = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float vj = val[j];
+                    gt += vj > vi;
+                    ge += vj >= vi;
+                }
+                if (gt < r && r <= ge) tau = vi;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tau = fmaxf(tau, __shfl_xor(tau, o));
+        }
+        __syncthreads();        // every lane has ranked against the raw logits
+        float Z = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const bool keep = r > 0 && val[i] >= tau;
+            const float w = keep ? expf(val[i] - smax) : 0.f;
+            val[i] = w;
+            pos[i] = kl[pos[i]];                  // key position -> key row
+            Z += w;
+        }
+        Z = wave_sum(Z);
+        const float Zt = on ? p.zab[slot] + Z : 0.f;
+        for (int e = 0; e < d_c && on; ++e) {
+            float a = 0.f;
+            for (int i = lane; i < n; i += 64)
+                if (val[i] > 0.f) a += val[i] * p.Xkp[(int64_t)pos[i] * p.DP + off_c + e];
+            a = wave_sum(a);
+            if (lane == 0) {
+                float *dst = p.out_code + (int64_t)qrow * p.D + off_c + e;
+                *dst = (Zt > 0.f) ? (*dst + a) / Zt : 0.f;
+            }
+        }
+        if (lane == 0 && on) {
+            if (p.out_tau) p.out_tau[(int64_t)qrow * p.C + c] = tau;
+            if (p.out_nvalid) p.out_nvalid[(int64_t)qrow * p.C + c] = p.nk[c];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 screening kernel (DDG_ATTN_BF16_FILTER, k <= DDG_MAX_TOPK_REG).
 //
@@ -448,12 +744,6 @@ extern "C" int ddg_debug_filt_stats(unsigned long long *out4, int reset) {
 #define FILT_NT (64 * FILT_NW)        // threads per workgroup
 #define QPBF (32 * FILT_NW)           // queries per workgroup
 #define FILT_EPS 8.0e-3f
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
 
 // sum over the 16 lanes of a DPP row, result in every lane: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
 __device__ __forceinline__ float row16_sum(float v) {
@@ -1297,6 +1587,8 @@ struct AttnWs {
     PairList L2, L3;           // fallback lists (128 per workgroup)
     float *st_val;             // parked lists of the screening path, FILT_GROUP workgroups
     int32_t *st_pos, *cand_pos, *cand_cnt, *st_ovf;
+    int32_t *lpos;             // window path (k > DDG_MAX_TOPK_REG): listed keys of WIN_GROUP workgroups
+    float *lval;
     size_t total;
     int64_t slots;             // capacity of every per-pair array
     int nchunk_k, nchunk_q;
@@ -1319,6 +1611,16 @@ static int64_t filt_chunk_fixed() {
     static const bool reload = [] { const char *e = getenv("DDG_FILT_CHUNK_RELOAD"); return e && e[0] == '1'; }();
     static const int64_t once = filt_chunk_parse();
     return reload ? filt_chunk_parse() : once;
+}
+
+// DDG_ATTN_RADIX=1: k > DDG_MAX_TOPK_REG goes through the 5-level radix select (six full passes) as in round 1;
+// DDG_WIN_CAP=n (tests): smaller lists, so that pairs overflow into the radix fallback.  Both read per call: the
+// path they steer runs for seconds.
+static bool window_path() { const char *e = getenv("DDG_ATTN_RADIX"); return !(e && e[0] == '1'); }
+static int win_cap() {
+    const char *e = getenv("DDG_WIN_CAP");
+    const int c = e ? atoi(e) : WIN_CAP;
+    return c < 1 ? 1 : (c > WIN_CAP ? WIN_CAP : c);
 }
 
 static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int D, int64_t k, bool same) {
@@ -1361,6 +1663,12 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
         w.cand_pos = (int32_t *)take(kk ? (size_t)grp * FILT_CAPH * FILT_NT * 4 : 0);
         w.cand_cnt = (int32_t *)take(kk ? (size_t)grp * FILT_NT * 4 : 0);
         w.st_ovf = (int32_t *)take(kk ? (size_t)grp * FILT_NT * 4 : 0);
+    }
+    {
+        const int64_t nb = w.slots / QPB + C;
+        const size_t ls = k > DDG_MAX_TOPK_REG ? (size_t)(nb < WIN_GROUP ? nb : WIN_GROUP) * QPB * WIN_CAP * 4 : 0;
+        w.lpos = (int32_t *)take(ls);
+        w.lval = (float *)take(ls);
     }
     w.total = o;
 }
@@ -1436,6 +1744,19 @@ static int run_select(AttnArgs &a, int64_t nb, int mode, hipStream_t s) {
     }
     if (NLIST(a.k) <= 16) return launch_attn<KS4, MODE_TOPK, 16>(a, nb, 0, s);
     if (a.k <= DDG_MAX_TOPK_REG) return launch_attn<KS4, MODE_TOPK, 32>(a, nb, 0, s);
+    if (mode == ATTN_WINDOW) {
+        // sample: range, then two bracketing histograms (the second 128x finer); full: the bracket's histogram
+        const size_t ex = (size_t)QPB * WHSTRIDE * 4;
+        a.sample = 1;
+        a.level = WIN_MINMAX;
+        if ((rc = launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s))) return rc;
+        a.level = WIN_SHIST;
+        if ((rc = launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s))) return rc;
+        if ((rc = launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s))) return rc;
+        a.sample = 0;
+        a.level = WIN_FULL;
+        return launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s);
+    }
     for (int L = 0; L < 5; ++L) {
         a.level = L;
         rc = launch_attn<KS4, MODE_HIST, 1>(a, nb, (size_t)QPB * HSTRIDE * 4, s);
@@ -1445,8 +1766,20 @@ static int run_select(AttnArgs &a, int64_t nb, int mode, hipStream_t s) {
 }
 
 template <int KS4>
-static int run_fill(AttnArgs &a, int64_t nb, int dcmax, hipStream_t s) {
+static int run_fill(AttnArgs &a, int64_t nb, int dcmax, bool window, hipStream_t s) {
     a.dcs = dcmax | 1;
+    if (window) {      // second full pass of the window path + the in-list selection, group by group
+        AttnArgs b = a;
+        for (int64_t g0 = 0; g0 < nb; g0 += WIN_GROUP) {
+            const int64_t gn = nb - g0 < WIN_GROUP ? nb - g0 : WIN_GROUP;
+            b.blk_lo = (int)g0;
+            int rc = launch_attn<KS4, MODE_WFILL, 1>(b, gn, (size_t)(QPB + 256 * a.dcs) * 4, s);
+            if (rc) return rc;
+            k_attn_wlist<<<(unsigned)gn, 256, 0, s>>>(b);
+        }
+        DDG_CHECK_LAUNCH();
+        return DDG_OK;
+    }
     return launch_attn<KS4, MODE_FILL, 1>(a, nb, (size_t)256 * a.dcs * 4, s);
 }
 
@@ -1460,12 +1793,12 @@ static int dispatch_select(AttnArgs &a, int64_t nb, int mode, int D, hipStream_t
     return DDG_E_UNSUPPORTED;
 }
 
-static int dispatch_fill(AttnArgs &a, int64_t nb, int dcmax, int D, hipStream_t s) {
+static int dispatch_fill(AttnArgs &a, int64_t nb, int dcmax, int D, hipStream_t s, bool window = false) {
     switch (ks4_for(D)) {
-        case 8: return run_fill<8>(a, nb, dcmax, s);
-        case 16: return run_fill<16>(a, nb, dcmax, s);
-        case 24: return run_fill<24>(a, nb, dcmax, s);
-        case 32: return run_fill<32>(a, nb, dcmax, s);
+        case 8: return run_fill<8>(a, nb, dcmax, window, s);
+        case 16: return run_fill<16>(a, nb, dcmax, window, s);
+        case 24: return run_fill<24>(a, nb, dcmax, window, s);
+        case 32: return run_fill<32>(a, nb, dcmax, window, s);
     }
     return DDG_E_UNSUPPORTED;
 }
@@ -1491,6 +1824,9 @@ static void attn_args(AttnArgs &a, const AttnWs &w, const PairList &l, int64_t N
     a.tau = l.tau; a.smax = l.smax; a.flag = l.flag; a.prefix = w.prefix; a.rank = w.rank;
     a.out_code = nullptr; a.out_tau = nullptr; a.out_nvalid = nullptr; a.Nk = Nk; a.C = C;
     a.D = D; a.DP = ks4_for(D) * 8; a.k = k; a.level = 0; a.dcs = 1;
+    // window-path state lives in arrays the k > DDG_MAX_TOPK_REG paths do not use otherwise (L3, prefix)
+    a.wlo = w.L3.tau; a.ww = w.L3.smax; a.wst = w.L3.flag; a.nab = w.L3.qlist;
+    a.zab = reinterpret_cast<float *>(w.prefix); a.lpos = w.lpos; a.lval = w.lval; a.sample = 0; a.wcap = win_cap();
 }
 
 // flagged pairs of `src` (workgroups of qpb_src pairs) -> `dst` (workgroups of 128)
@@ -1585,6 +1921,7 @@ extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, 
     const int kk = (int)(k > Nk ? Nk : k);
     attn_args(a, w, w.L1, Nk, C, D, kk);
     a.out_code = out_code;
+    if (kk > DDG_MAX_TOPK_REG && window_path()) mode = ATTN_WINDOW;
     return dispatch_select(a, blocks_max(w, C, primary_qpb(mode, kk)), mode, D, s);
 }
 
@@ -1617,6 +1954,13 @@ extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk
     if (kk > DDG_MAX_TOPK_REG) {
         attn_args(a, w, w.L1, Nk, C, D, kk);
         a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
+        if (!window_path()) return dispatch_fill(a, nb128, dcmax, D, s);
+        if ((rc = dispatch_fill(a, nb128, dcmax, D, s, true))) return rc;
+        // pairs whose bracket missed the k-th logit (or whose bin overflowed the list): radix select + threshold pass
+        if ((rc = compact_pairs(w, w.L1, QPB, w.L2, C, s))) return rc;
+        attn_args(a, w, w.L2, Nk, C, D, kk);
+        a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
+        if ((rc = dispatch_select(a, nb128, DDG_ATTN_F32, D, s))) return rc;
         return dispatch_fill(a, nb128, dcmax, D, s);
     }
     const int qpb = primary_qpb(mode, kk);

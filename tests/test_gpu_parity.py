@@ -512,3 +512,41 @@ def test_attn_large_k_at_scale(dev):
                 assert np.all(np.abs(got - ref) <= slack), (j, c, np.abs(got - ref).max(), slack.max())
             checked += 1
     assert checked >= 12
+
+
+@pytest.mark.parametrize("rows,k,cap", [
+    (40_000, 2_000, None),        # top_k = 0.05: sampled bracket (stride 2), two full passes
+    (40_000, 31, None),           # smallest k of the path: the bracket has no upper edge
+    (40_000, 28_000, None),       # most keys kept
+    (40_000, 2_000, "3"),         # lists of 3 entries: most pairs overflow into the radix fallback
+    (3_000, 150, None),           # fewer keys than the sample size: the "sample" is every key
+])
+def test_attn_window_path_equals_radix(dev, rows, k, cap):
+    """k > DDG_MAX_TOPK_REG: the window selection (sample bracket -> one histogram pass -> accumulate + exact in-list
+    selection) against the 5-level radix select of round 1 on the same arithmetic: the k-th logit must be the SAME
+    float, the fills equal up to summation order.  The radix path itself is held to the fp64 closed form in
+    test_attn_large_k_at_scale / test_attn_fill_synthetic."""
+    ops = _ops()
+    from ddgani_amd import synth
+    tab = synth.make_table("c3", dev, rows=rows)
+    lo, hi = rows // 3, rows // 3 + 384
+    Xq, mq = tab.X_attn[lo:hi].contiguous(), tab.m8[lo:hi].contiguous()
+    res = {}
+    for radix in ("1", "0"):
+        os.environ["DDG_ATTN_RADIX"] = radix
+        if cap and radix == "0":
+            os.environ["DDG_WIN_CAP"] = cap
+        try:
+            o, t, nv = ops.attn_topk_fill(Xq, mq, tab.X_attn, tab.m8, tab.W, tab.layout, k, q_row_offset=lo, debug=True,
+                                          mode=0)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DDG_ATTN_RADIX", None)
+            os.environ.pop("DDG_WIN_CAP", None)
+        res[radix] = (o, t, nv)
+    (o1, t1, n1), (o0, t0, n0) = res["1"], res["0"]
+    assert torch.equal(n1, n0)
+    fin = ~torch.isnan(t1)
+    assert torch.equal(torch.isnan(t0), torch.isnan(t1)) and int(fin.sum()) > 1000
+    assert torch.equal(t0[fin], t1[fin])                                  # the same k-th logit, bit for bit
+    assert float((o0 - o1).abs().max()) <= 2e-6
