@@ -283,18 +283,30 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         sel = sum(sel_ms) / len(sel_ms)
-        n_launch = 1 if k <= ops.MAX_TOPK_REG else 5                      # radix select = 5 launches of the same kernel
+        fil = sum(fill_ms) / len(fill_ms)
+        large_k = k > ops.MAX_TOPK_REG                                      # window selection in either mode
+        radix = large_k and os.environ.get("DDG_ATTN_RADIX") == "1"
+        win_f32 = large_k and os.environ.get("DDG_WIN_F32") == "1"
+        n_launch = 5 if radix else 1                                        # radix select = 5 launches of the same kernel
         flops = 2.0 * lay.D * pairs_local
-        achieved = flops / (sel / n_launch * 1e-3) / 1e12
-        filt = amode == ops.ATTN_BF16_FILTER and k <= ops.MAX_TOPK_REG      # larger k: fp32 radix select in either mode
+        kernel_ms = sel / n_launch
+        if large_k and not radix:
+            # two full similarity passes (bracket histogram in the select phase, accumulation in the fill phase); the
+            # three sampled passes of the select phase (about 1 % of the keys each) are in the time, not in the flops
+            kernel_ms = (sel + fil) / 2
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        filt = amode == ops.ATTN_BF16_FILTER and not large_k
         kname = ("void k_attn_screen<", "void k_attn_rescore<", "void k_attn_warm<") if filt else "void k_attn<"
-        peak = PEAK_BF16_MFMA_TFLOPS if filt else PEAK_F32_MFMA_TFLOPS
+        # split passes execute three f16 products per algorithmic multiply-add: algorithmic flops against a third of the f16 peak
+        peak = PEAK_BF16_MFMA_TFLOPS if filt else (PEAK_BF16_MFMA_TFLOPS / 3 if large_k and not radix and not win_f32 else PEAK_F32_MFMA_TFLOPS)
         traffic, traffic_src = pmc_traffic(a.workload, N, kname) if world == 1 else (None, None)
         res = {
             "metric": "imputed rows/sec (T-step reverse diffusion + top_k attn fill)",
             "value": N / (dt / a.steps), "unit": "rows/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (bf16 MFMA screening, exact fp32 re-scoring of every candidate)" if filt else "f32",
+            "dtype": ("f32 (bf16 MFMA screening, exact fp32 re-scoring of every candidate)" if filt else
+                      "f32 (logits on the f16 MFMA from operands split in two halves, error 3 * 2^-22 sum|q||k|; fp32 accumulation)"
+                      if large_k and not radix and not win_f32 else "f32"),
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl['desc']}" + (f" [rows overridden to {N}]" if a.rows else ""),
                        "rows": N, "cols": lay.C, "encoded_dim": lay.D, "top_k": k, "T": T,
@@ -304,14 +316,17 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("k_attn_screen (bf16 MFMA similarity screening; its time here includes the exact fp32 "
                                     "k_attn_rescore and k_attn_warm launches of the select phase, about 12 % of it)" if filt else
-                                    "k_attn<MODE_HIST> (fp32 MFMA similarity, 5-level radix select of the k-th logit)" if k > ops.MAX_TOPK_REG else
+                                    "k_attn<MODE_HIST> (fp32 MFMA similarity, 5-level radix select of the k-th logit)" if radix else
+                                    "k_attn<MODE_WIN> + k_attn<MODE_WFILL> (window selection: two full similarity passes, "
+                                    + ("fp32 MFMA)" if win_f32 else "f16 MFMA on split operands; peak = dense f16 peak / 3 products)") if large_k else
                                     "k_attn<MODE_TOPK> (fp32 MFMA similarity + top-k + fill)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
-                         "flops_per_launch": flops, "launch_ms": sel / n_launch,
+                         "flops_per_launch": flops, "launch_ms": kernel_ms,
                          "launches_note": ("one 'launch' = all key-chunk x workgroup-group launches of the select phase of one "
                                            "step (k_attn_warm once per group, then k_attn_screen + k_attn_rescore per chunk), "
                                            "timed together with HIP events on the launch stream; flops count only the "
-                                           "2*D*pairs*keys of the similarity") if filt else "one launch per step"},
+                                           "2*D*pairs*keys of the similarity") if filt else
+                                          "launch_ms = (select + fill phases) / 2: one full pass each" if large_k and not radix else "one launch per step"},
         }
         if world == 1:
             res["roofline_other_kernels"] = other_rooflines(ops, P, xd, Md, lay, T, sched_host)

@@ -60,6 +60,8 @@ static_assert(NLIST(DDG_MAX_TOPK_REG) <= 32, "register lists hold at most 32 ent
 struct AttnArgs {
     const float *Xkp, *Xqp, *Wp;
     const __bf16 *Xkh;         // [Nk][DP] bf16(Xkp) (filter kernel)
+    const _Float16 *Xks;       // [Nk][2 DP] two-half f16 split of kscale * Xkp: DP leading halves, DP scaled remainders
+    const float *kscale;       // [1] power of two that brings the largest |key element| into [0.5, 1)
     const float *kmax;         // [1] largest key 2-norm (filter kernel)
     float *st_val;             // filter kernel: top-(k+1) lists parked between key-chunk launches,
     int32_t *st_pos;           //   [block - blk_lo][k+1][FILT_NT threads]
@@ -213,9 +215,19 @@ __device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP
     topk_output<KCAP>(p, lst, lpos, slot, qrow, nk, kl, off_c, d_c, DP, h);
 }
 
-template <int KS4, int MODE, int KCAP>
+// SPLIT (window passes only): the logits come from the f16 MFMA on operands split in two halves,
+//   x = hi + 2^-11 lo,  hi = f16(x), lo = f16(2^11 (x - hi))      (both operands pre-scaled by powers of two into f16 range)
+//   x y ~ hi_x hi_y + 2^-11 (lo_x hi_y + hi_x lo_y)               (the 2^-22 lo_x lo_y term is dropped; two accumulators)
+// three v_mfma_f32_32x32x16_f16 per 16-deep step instead of eight v_mfma_f32_32x32x2_f32 (a sixteenth of the matrix
+// time each), fp32 accumulation.  |error| <= 3 * 2^-22 sum_d |q_d||k_d| + fp32 accumulation, the class of the fp32
+// chain's own rounding; the key tiles keep their byte size (4 bytes per element), so the staging is shared.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int KS4, int MODE, int KCAP, bool SPLIT = false>
 __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
+    static_assert(!SPLIT || MODE == MODE_WIN || MODE == MODE_WFILL, "split arithmetic: window passes only");
     constexpr int DP = KS4 * 8;
+    constexpr int KS = KS4 / 2;            // 16-deep steps (SPLIT)
+    constexpr int XOFF = (SPLIT && MODE == MODE_WFILL) ? 512 : 0;      // floats of the two fp32 side tiles (MODE_WFILL)
     constexpr int LSTR = DP + 4;
     constexpr int NPF = KS4 / 4;           // float4 prefetch registers per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -247,8 +259,45 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     const int qrow = p.qlist[slot];
 
     // ---- query operand in registers: breg[4u+s] = W[c][k] * x_q[k], k = 8u + 4h + s
-    float breg[KS4 * 4];
-    {
+    f16x8 bh[SPLIT ? KS : 1], bl[SPLIT ? KS : 1];
+    float qinv = 1.f;                      // SPLIT: logit = accumulator * qinv
+    if constexpr (SPLIT) {
+        // q_d = W[c][d] x_q[d] for d = 16 u + 8 h + j, scaled by a power of two so that max |q_d| lies in [2^13, 2^14)
+        const float *wq = p.Wp + (int64_t)c * DP + 8 * h;
+        const float *xq = p.Xqp + (int64_t)(qrow < 0 ? 0 : qrow) * DP + 8 * h;
+        float qmax = 0.f;
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 16 * u + 4 * j4);
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xq + 16 * u + 4 * j4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qmax = fmaxf(qmax, fabsf(wv[j] * xv[j]));
+            }
+        qmax = fmaxf(qmax, __shfl_xor(qmax, 32));
+        int eq = 0;
+        if (qmax > 0.f && qrow >= 0) frexpf(qmax, &eq); else eq = 14;
+        const float qsc = ldexpf(1.f, 14 - eq);
+        qinv = ldexpf(1.f, eq - 14) / p.kscale[0];
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 16 * u + 4 * j4);
+                f32x4 xv = *reinterpret_cast<const f32x4 *>(xq + 16 * u + 4 * j4);
+                if (qrow < 0) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float q = wv[j] * xv[j] * qsc;
+                    const _Float16 qh = (_Float16)q;
+                    bh[u][4 * j4 + j] = qh;
+                    bl[u][4 * j4 + j] = (_Float16)((q - (float)qh) * 2048.f);
+                }
+            }
+    }
+    float breg[SPLIT ? 1 : KS4 * 4];
+    if constexpr (!SPLIT) {
         const float *wq = p.Wp + (int64_t)c * DP + 4 * h;
         const float *xq = p.Xqp + (int64_t)(qrow < 0 ? 0 : qrow) * DP + 4 * h;
 #pragma unroll
@@ -323,7 +372,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) accr[e] = 0.f;
         if (d_c > 8) {
-            float *accb = extra + QPB + (int64_t)tid * p.dcs;
+            float *accb = extra + QPB + XOFF + (int64_t)tid * p.dcs;
             for (int e = 0; e < d_c; ++e) accb[e] = 0.f;
         }
     }
@@ -331,20 +380,29 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     // ---- key streaming
     const int st_row = tid >> 3, st_c = tid & 7;
     f32x4 pf[NPF];
+    float pfx = 0.f;                       // SPLIT + MODE_WFILL: fp32 value st_c of the key row's column block (side tile)
+    float *xs0 = extra + QPB, *xs1 = extra + QPB + 256;
+    const float *ksrc = SPLIT ? reinterpret_cast<const float *>(p.Xks) : p.Xkp;     // rows of DP * 4 bytes either way
     auto prefetch = [&](int t) {
+#ifdef EXP_NOLOAD      // timing experiments only (wrong results): every tile re-reads the first rows
+        const int pos = (t & 1) * TK + st_row;
+#else
         const int pos = t * TK + st_row;
+#endif
         const int kidx = pos < nk ? kl[(int64_t)pos * kstride] : -1;
-        const float *src = p.Xkp + (int64_t)(kidx < 0 ? 0 : kidx) * DP + st_c * 4;
+        const float *src = ksrc + (int64_t)(kidx < 0 ? 0 : kidx) * DP + st_c * 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             pf[i] = *reinterpret_cast<const f32x4 *>(src + 32 * i);
             if (kidx < 0) pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (SPLIT && MODE == MODE_WFILL) pfx = (kidx >= 0 && st_c < d_c) ? p.Xkp[(int64_t)kidx * DP + off_c + st_c] : 0.f;
     };
     auto commit = [&](float *buf) {
         float *dst = buf + st_row * LSTR + st_c * 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) *reinterpret_cast<f32x4 *>(dst + 32 * i) = pf[i];
+        if (SPLIT && MODE == MODE_WFILL) (buf == kbuf0 ? xs0 : xs1)[tid] = pfx;
     };
 
     const int ntk = (nk + TK - 1) / TK;
@@ -360,17 +418,40 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.f;
         const float *Ab = cur + r32 * LSTR + 4 * h;
+        if constexpr (SPLIT) {
+            // two independent chains: leading products, and the cross products that carry a factor 2^-11
+            f32x16 accx;
 #pragma unroll
-        for (int u = 0; u < KS4; ++u) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Ab + 8 * u);
+            for (int g = 0; g < 16; ++g) accx[g] = 0.f;
+            const float qinvx = qinv * 0x1p-11f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], breg[4 * u + s], acc, 0, 0, 0);
+            for (int u = 0; u < KS; ++u) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab + 8 * u);            // halves 16 u + 8 h ..
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(Ab + DP / 2 + 8 * u);   // their remainders
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], accx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = fmaf(accx[g], qinvx, acc[g] * qinv);
+        } else {
+#pragma unroll
+            for (int u = 0; u < KS4; ++u) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Ab + 8 * u);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], breg[4 * u + s], acc, 0, 0, 0);
+            }
         }
 
         const int rem = nk - t * TK;          // valid key rows in this tile (>= 1)
         const bool full = rem >= TK;
 
+#ifdef EXP_NOEPI       // timing experiments only (wrong results): no per-logit work
+        if (MODE == MODE_WIN || MODE == MODE_WFILL) {
+            smax = fmaxf(smax, acc[0] + acc[5] + acc[15]);
+        } else
+#endif
         if constexpr (MODE == MODE_TOPK) {
             float thr = lst[KCAP - 1];
 #pragma unroll
@@ -430,7 +511,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             if (!full) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g)
-                    if ((g & 3) + 8 * (g >> 2) + 4 * h >= rem) acc[g] = -INFINITY;     // tt = -inf or NaN: neither kept nor listed
+                    if ((g & 3) + 8 * (g >> 2) + 4 * h >= rem) acc[g] = NAN;           // tt = NaN: neither kept nor listed
             }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -440,16 +521,26 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                 const bool keep = tt >= fb1;
                 const float w = keep ? __builtin_amdgcn_exp2f((v - smax) * 1.44269504088896340736f) : 0.f;
                 Z += w;
-                const float *xr = cur + kr * LSTR + off_c;
+                // fp32 values of the key row's column block: from the tile itself, or (SPLIT) from the side tile /
+                // for blocks wider than it, rebuilt from the two halves
+                const float *xr = SPLIT ? (cur == kbuf0 ? xs0 : xs1) + kr * 8 : cur + kr * LSTR + off_c;
                 if (d_c == 1) {
                     accr[0] += w * xr[0];
                 } else if (d_c <= 8) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) accr[e] += w * xr[e];      // e >= d_c: finite neighbours, never read back
+                    for (int e = 0; e < 8; ++e) accr[e] += w * xr[e];      // e >= d_c: finite neighbours / zeros, never read back
                 } else {
-                    float *accb = extra + QPB + (int64_t)tid * p.dcs;
-                    if (__any(keep))
-                        for (int e = 0; e < d_c; ++e) accb[e] += w * xr[e];
+                    float *accb = extra + QPB + XOFF + (int64_t)tid * p.dcs;
+                    if (__any(keep)) {
+                        if constexpr (SPLIT) {
+                            const _Float16 *hr = reinterpret_cast<const _Float16 *>(cur + kr * LSTR) + off_c;
+                            const float kinv = 1.f / p.kscale[0];
+                            for (int e = 0; e < d_c; ++e)
+                                accb[e] += w * (((float)hr[e] + (float)hr[DP + e] * 0x1p-11f) * kinv);
+                        } else {
+                            for (int e = 0; e < d_c; ++e) accb[e] += w * xr[e];
+                        }
+                    }
                 }
                 const bool inb = tt >= fb && !keep;
                 if (__any(inb)) {
@@ -577,8 +668,8 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         } else {
             __syncthreads();
             if (h == 0 && active) {
-                const float *a0 = extra + QPB + (int64_t)tid * p.dcs;
-                const float *a1 = extra + QPB + (int64_t)(tid + 32) * p.dcs;
+                const float *a0 = extra + QPB + XOFF + (int64_t)tid * p.dcs;
+                const float *a1 = extra + QPB + XOFF + (int64_t)(tid + 32) * p.dcs;
                 for (int e = 0; e < d_c; ++e) p.out_code[(int64_t)qrow * p.D + off_c + e] = a0[e] + a1[e];
             }
         }
@@ -1408,6 +1499,36 @@ __global__ void k_keys_bf16(const float *__restrict__ Xkp, int64_t rows, int DP,
     if (lane == 0) atomicMax(kmax_bits, __float_as_uint(best));     // non-negative floats order like their bits
 }
 
+// largest |element| of the padded keys (non-negative floats order like their bits)
+__global__ void k_maxabs(const float *__restrict__ X, int64_t n, unsigned *__restrict__ out_bits) {
+    float best = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        best = fmaxf(best, fabsf(X[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(best));
+}
+
+// keys -> two f16 halves of kscale * x per element (row = DP leading halves, then DP remainders scaled by 2^11);
+// kscale = the power of two that brings the largest |element| into [0.5, 1), written to kscale_out by every thread
+__global__ void k_keys_split(const float *__restrict__ Xkp, int64_t rows, int DP, _Float16 *__restrict__ Xks,
+                             const unsigned *__restrict__ max_bits, float *__restrict__ kscale_out) {
+    const float mx = __uint_as_float(max_bits[0]);
+    int e2 = 0;
+    if (mx > 0.f && mx < INFINITY) frexpf(mx, &e2);
+    const float ksc = ldexpf(1.f, -e2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) kscale_out[0] = ksc;
+    const int64_t n = rows * DP;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / DP;
+        const int k = (int)(e - r * DP);
+        const float x = Xkp[e] * ksc;
+        const _Float16 hi = (_Float16)x;
+        Xks[r * 2 * DP + k] = hi;
+        Xks[r * 2 * DP + DP + k] = (_Float16)((x - (float)hi) * 2048.f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // preparation kernels: padding and per-column index lists
 // ---------------------------------------------------------------------------------------------
@@ -1578,7 +1699,7 @@ struct PairList {
 
 struct AttnWs {
     float *Xkp, *Xqp, *Wp;
-    __bf16 *Xkh;
+    __bf16 *Xkh;               // bf16 keys (k <= DDG_MAX_TOPK_REG) or their two-half f16 split (larger k): one region
     int32_t *klist, *nk, *obs_q, *cnt_k, *cnt_q, *offsets;
     uint32_t *prefix;
     int32_t *rank;
@@ -1616,7 +1737,18 @@ static int64_t filt_chunk_fixed() {
 // DDG_ATTN_RADIX=1: k > DDG_MAX_TOPK_REG goes through the 5-level radix select (six full passes) as in round 1;
 // DDG_WIN_CAP=n (tests): smaller lists, so that pairs overflow into the radix fallback.  Both read per call: the
 // path they steer runs for seconds.
-static bool window_path() { const char *e = getenv("DDG_ATTN_RADIX"); return !(e && e[0] == '1'); }
+// Tables of fewer than WIN_MIN_KEYS rows keep the radix path as well (DDG_ATTN_WINDOW=1 overrides, tests): six passes
+// cost milliseconds there, and its accumulation order is the one whose rounding reproduces the reference's votes on
+// the exactly tied categorical cells of tests/golden/e2e_hospital (a different summation order flips such an arg-max).
+#define WIN_MIN_KEYS (2 * WIN_SAMPLE)
+static bool window_path(int64_t Nk) {
+    const char *e = getenv("DDG_ATTN_RADIX");
+    if (e && e[0] == '1') return false;
+    const char *f = getenv("DDG_ATTN_WINDOW");
+    return Nk >= WIN_MIN_KEYS || (f && f[0] == '1');
+}
+// DDG_WIN_F32=1: the window passes on the fp32 MFMA chain (the radix path's arithmetic) instead of the f16 split
+static bool window_f32() { const char *e = getenv("DDG_WIN_F32"); return e && e[0] == '1'; }
 static int win_cap() {
     const char *e = getenv("DDG_WIN_CAP");
     const int c = e ? atoi(e) : WIN_CAP;
@@ -1633,7 +1765,7 @@ static void attn_carve(AttnWs &w, char *base, int64_t Nq, int64_t Nk, int C, int
     w.Xkp = (float *)take((size_t)Nk * DP * 4);
     w.Xqp = (float *)take((size_t)Nq * DP * 4);
     if (same) w.Xqp = w.Xkp;
-    w.Xkh = (__bf16 *)take((size_t)Nk * DP * 2);
+    w.Xkh = (__bf16 *)take((size_t)Nk * DP * (k > DDG_MAX_TOPK_REG ? 4 : 2));
     w.Wp = (float *)take((size_t)C * DP * 4);
     w.klist = (int32_t *)take((size_t)C * Nk * 4);
     w.nk = (int32_t *)take((size_t)C * 4);
@@ -1695,13 +1827,13 @@ static int set_lds_attr(const void *fn, size_t lds, std::atomic<size_t> &granted
     return DDG_OK;
 }
 
-template <int KS4, int MODE, int KCAP>
+template <int KS4, int MODE, int KCAP, bool SPLIT = false>
 static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_bytes, hipStream_t s) {
     const size_t lds = (size_t)2 * TK * (KS4 * 8 + 4) * 4 + extra_bytes;
     static std::atomic<size_t> granted{48 * 1024};
-    int rc = set_lds_attr((const void *)k_attn<KS4, MODE, KCAP>, lds, granted);
+    int rc = set_lds_attr((const void *)k_attn<KS4, MODE, KCAP, SPLIT>, lds, granted);
     if (rc) return rc;
-    k_attn<KS4, MODE, KCAP><<<(unsigned)nblocks_max, 256, lds, s>>>(a);
+    k_attn<KS4, MODE, KCAP, SPLIT><<<(unsigned)nblocks_max, 256, lds, s>>>(a);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
@@ -1747,15 +1879,16 @@ static int run_select(AttnArgs &a, int64_t nb, int mode, hipStream_t s) {
     if (mode == ATTN_WINDOW) {
         // sample: range, then two bracketing histograms (the second 128x finer); full: the bracket's histogram
         const size_t ex = (size_t)QPB * WHSTRIDE * 4;
-        a.sample = 1;
-        a.level = WIN_MINMAX;
-        if ((rc = launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s))) return rc;
-        a.level = WIN_SHIST;
-        if ((rc = launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s))) return rc;
-        if ((rc = launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s))) return rc;
-        a.sample = 0;
-        a.level = WIN_FULL;
-        return launch_attn<KS4, MODE_WIN, 1>(a, nb, ex, s);
+        const bool f32 = window_f32();
+        auto pass = [&](int level, int sample) {
+            a.level = level;
+            a.sample = sample;
+            return f32 ? launch_attn<KS4, MODE_WIN, 1, false>(a, nb, ex, s) : launch_attn<KS4, MODE_WIN, 1, true>(a, nb, ex, s);
+        };
+        if ((rc = pass(WIN_MINMAX, 1))) return rc;
+        if ((rc = pass(WIN_SHIST, 1))) return rc;
+        if ((rc = pass(WIN_SHIST, 1))) return rc;
+        return pass(WIN_FULL, 0);
     }
     for (int L = 0; L < 5; ++L) {
         a.level = L;
@@ -1773,7 +1906,8 @@ static int run_fill(AttnArgs &a, int64_t nb, int dcmax, bool window, hipStream_t
         for (int64_t g0 = 0; g0 < nb; g0 += WIN_GROUP) {
             const int64_t gn = nb - g0 < WIN_GROUP ? nb - g0 : WIN_GROUP;
             b.blk_lo = (int)g0;
-            int rc = launch_attn<KS4, MODE_WFILL, 1>(b, gn, (size_t)(QPB + 256 * a.dcs) * 4, s);
+            int rc = window_f32() ? launch_attn<KS4, MODE_WFILL, 1, false>(b, gn, (size_t)(QPB + 256 * a.dcs) * 4, s)
+                                  : launch_attn<KS4, MODE_WFILL, 1, true>(b, gn, (size_t)(QPB + 512 + 256 * a.dcs) * 4, s);
             if (rc) return rc;
             k_attn_wlist<<<(unsigned)gn, 256, 0, s>>>(b);
         }
@@ -1818,6 +1952,7 @@ static inline int primary_qpb(int mode, int64_t k) {
 static inline int64_t blocks_max(const AttnWs &w, int C, int qpb) { return w.slots / qpb + C; }
 
 static void attn_args(AttnArgs &a, const AttnWs &w, const PairList &l, int64_t Nk, int C, int D, int k) {
+    a.Xks = reinterpret_cast<const _Float16 *>(w.Xkh); a.kscale = reinterpret_cast<const float *>(w.flags + 3);
     a.Xkp = w.Xkp; a.Xqp = w.Xqp; a.Wp = w.Wp; a.Xkh = w.Xkh; a.kmax = reinterpret_cast<const float *>(w.flags + 1);
     a.st_val = w.st_val; a.st_pos = w.st_pos; a.cand_pos = w.cand_pos; a.cand_cnt = w.cand_cnt; a.st_ovf = w.st_ovf; a.key_lo = 0; a.key_hi = 0x7fffffff; a.blk_lo = 0;
     a.klist = w.klist; a.nk = w.nk; a.qlist = l.qlist; a.qb_start = l.qb_start; a.offsets = w.offsets;
@@ -1868,7 +2003,7 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
     if (hipMemcpyAsync(w.offsets, offsets_host, (size_t)(C + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess)
         return DDG_E_LAUNCH;
     if (hipMemsetAsync(w.L1.qlist, 0xFF, (size_t)w.slots * 4, s) != hipSuccess) return DDG_E_LAUNCH;
-    if (hipMemsetAsync(w.flags, 0, 8, s) != hipSuccess) return DDG_E_LAUNCH;
+    if (hipMemsetAsync(w.flags, 0, 16, s) != hipSuccess) return DDG_E_LAUNCH;
     if (same && hipMemsetAsync(w.flags, 1, 1, s) != hipSuccess) return DDG_E_LAUNCH;
 
     auto egrid = [](int64_t n) { int64_t g = ceil_div64(n, 256); return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); };
@@ -1877,6 +2012,12 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
     k_pad_rows<<<egrid((int64_t)C * DP), 256, 0, s>>>(W, w.Wp, C, D, DP);
     if (qpb == QPBF)
         k_keys_bf16<<<egrid(Nk * 64), 256, 0, s>>>(w.Xkp, Nk, DP, w.Xkh, reinterpret_cast<unsigned *>(w.flags + 1));
+    if ((k > Nk ? Nk : k) > DDG_MAX_TOPK_REG && window_path(Nk) && !window_f32()) {
+        k_maxabs<<<egrid(Nk * DP), 256, 0, s>>>(w.Xkp, Nk * DP, reinterpret_cast<unsigned *>(w.flags + 2));
+        k_keys_split<<<egrid(Nk * DP), 256, 0, s>>>(w.Xkp, Nk, DP, reinterpret_cast<_Float16 *>(w.Xkh),
+                                                    reinterpret_cast<const unsigned *>(w.flags + 2),
+                                                    reinterpret_cast<float *>(w.flags + 3));
+    }
 
     k_count_obs<<<w.nchunk_k, 256, 0, s>>>(mk, Nk, C, w.nchunk_k, w.cnt_k);
     k_scan_chunks<<<C, 256, 0, s>>>(w.cnt_k, w.nchunk_k, w.nk);
@@ -1921,7 +2062,7 @@ extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, 
     const int kk = (int)(k > Nk ? Nk : k);
     attn_args(a, w, w.L1, Nk, C, D, kk);
     a.out_code = out_code;
-    if (kk > DDG_MAX_TOPK_REG && window_path()) mode = ATTN_WINDOW;
+    if (kk > DDG_MAX_TOPK_REG && window_path(Nk)) mode = ATTN_WINDOW;
     return dispatch_select(a, blocks_max(w, C, primary_qpb(mode, kk)), mode, D, s);
 }
 
@@ -1954,7 +2095,7 @@ extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk
     if (kk > DDG_MAX_TOPK_REG) {
         attn_args(a, w, w.L1, Nk, C, D, kk);
         a.out_code = out_code; a.out_tau = out_tau; a.out_nvalid = out_nvalid;
-        if (!window_path()) return dispatch_fill(a, nb128, dcmax, D, s);
+        if (!window_path(Nk)) return dispatch_fill(a, nb128, dcmax, D, s);
         if ((rc = dispatch_fill(a, nb128, dcmax, D, s, true))) return rc;
         // pairs whose bracket missed the k-th logit (or whose bin overflowed the list): radix select + threshold pass
         if ((rc = compact_pairs(w, w.L1, QPB, w.L2, C, s))) return rc;
