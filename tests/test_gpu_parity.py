@@ -590,3 +590,61 @@ def test_attn_window_path_equals_radix(dev, rows, k, cap, arith):
         bad = (cell > 1e-5) & fin
         assert int(bad.sum()) <= 0.02 * int(fin.sum()), (int(bad.sum()), int(fin.sum()))
         assert float(cell[fin].max()) < 2.0 / k + 1e-3      # a flipped near-tie moves one key of k in or out
+
+
+def test_attn_large_k_c3_full_size(dev):
+    """BASELINE configuration c3 at its full size under the reference's own top_k (param.json: 0.05 -> k = 50 000 of
+    1M rows): a shard of 256 query rows against all keys.  Window selection (f16 split arithmetic) against the fp32
+    radix path -- the k-th logit within 2e-7, fills within 1e-5 apart from flipped near-ties -- and spot pairs against an fp64 closed form with the
+    near-tie slack of test_attn_large_k_at_scale."""
+    ops = _ops()
+    from ddgani_amd import synth
+    rows, k = 1_000_000, 50_000
+    tab = synth.make_table("c3", dev, rows=rows)
+    lo, hi = 500_000, 500_256
+    Xq, mq = tab.X_attn[lo:hi].contiguous(), tab.m8[lo:hi].contiguous()
+    res = {}
+    for radix in ("1", "0"):
+        os.environ["DDG_ATTN_RADIX"] = radix
+        try:
+            o, t, nv = ops.attn_topk_fill(Xq, mq, tab.X_attn, tab.m8, tab.W, tab.layout, k, q_row_offset=lo, debug=True,
+                                          mode=1)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DDG_ATTN_RADIX", None)
+        res[radix] = (o, t, nv)
+    (o1, t1, n1), (o0, t0, n0) = res["1"], res["0"]
+    fin = ~torch.isnan(t1)
+    assert torch.equal(n1, n0) and torch.equal(torch.isnan(t0), torch.isnan(t1)) and int(fin.sum()) > 2000
+    assert float((t0[fin] - t1[fin]).abs().max()) <= 2e-7
+    # a k-th logit closer than the two arithmetics' difference to its neighbour moves ONE key of k in or out of the kept
+    # set (exempt: within 1e-6 of the k-th logit): such a cell shifts by at most (value spread) / k
+    d = (o0 - o1).abs()
+    assert float((d > 1e-5).float().mean()) < 0.01
+    assert float(d.max()) <= 1e-5 + 8.0 / k
+    X64 = tab.X_attn.double()
+    W64 = tab.W.double()
+    m = tab.m8
+    off = tab.layout.offsets
+    mq_h = mq.cpu().numpy()
+    rng = np.random.default_rng(11)
+    with_missing = np.where((mq_h == 0).any(1))[0]
+    checked = 0
+    for j in rng.choice(with_missing, 4, replace=False):
+        for c in np.where(mq_h[j] == 0)[0][:2]:
+            keys = torch.nonzero(m[:, c] == 1).flatten()
+            keys = keys[keys != lo + j]
+            s = (X64[keys] @ (W64[c] * X64[lo + j])).cpu().numpy()
+            kth = np.partition(s, len(s) - k)[len(s) - k]
+            xv = X64[keys][:, off[c]:off[c + 1]].cpu().numpy()
+            keep = s >= kth
+            w = np.exp(s - s.max())
+            Z = w[keep].sum()
+            ref = (w[keep] @ xv[keep]) / Z
+            band = np.abs(s - kth) <= 1e-6
+            slack = (w[band, None] * np.abs(xv[band] - ref)).sum(0) / Z + 1e-5
+            assert abs(float(t0[j, c]) - kth) <= 1e-6, (j, c, float(t0[j, c]), kth)
+            got = o0[j, off[c]:off[c + 1]].double().cpu().numpy()
+            assert np.all(np.abs(got - ref) <= slack), (j, c, np.abs(got - ref).max(), slack.max())
+            checked += 1
+    assert checked >= 6
