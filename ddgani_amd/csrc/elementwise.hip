@@ -98,7 +98,7 @@ __global__ void k_forward_noise_rows(const float *__restrict__ x0, const float *
     const int64_t n = rows * D;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / D;
-        const int ti = (int)t[r] - 1;
+        const int ti = min(max((int)t[r], 1), T) - 1;      // a timestep outside [1, T] is clamped (torch would raise)
         const float ca = sched[6 * T + ti], cb = sched[7 * T + ti];
         float ev;
         if (eps) ev = eps[e];

@@ -28,6 +28,7 @@ struct LinArgs {
     const float *emb;
     const int64_t *t;
     int t_uniform;
+    int emb_rows;              // rows of emb: a timestep outside [0, emb_rows) is clamped (torch would raise)
     const float *scale, *shift;
     const uint8_t *drop;
     float drop_p;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs p) {
             const int64_t row = row0 + st_r + 32 * i;
             trows[i] = 0;
             if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
-                trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
+                trows[i] = min(max(p.t ? (int)p.t[row] : p.t_uniform, 0), p.emb_rows - 1);
         }
 
         auto stage = [&](int buf, int chunk) {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
             const int64_t row = row0 + st_r + RPP * i;
             trows[i] = 0;
             if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
-                trows[i] = p.t ? (int)p.t[row] : p.t_uniform;
+                trows[i] = min(max(p.t ? (int)p.t[row] : p.t_uniform, 0), p.emb_rows - 1);
         }
 
         f32x4 pa[NPA], pb[NPB];
@@ -462,10 +463,10 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
     return DDG_OK;
 }
 
-extern "C" int ddg_linear(const float *A, const float *A2, int in1, const float *W, const float *bias, int prologue,
-                          const float *emb, const int64_t *t, int t_uniform, const float *scale, const float *shift,
-                          const uint8_t *drop, float drop_p, uint64_t seed, uint64_t stream_id, float *Y,
-                          double *stats, int64_t rows, int in, int out, void *stream) {
+static int linear_impl(const float *A, const float *A2, int in1, const float *W, const float *bias, int prologue,
+                       const float *emb, int emb_rows, const int64_t *t, int t_uniform, const float *scale,
+                       const float *shift, const uint8_t *drop, float drop_p, uint64_t seed, uint64_t stream_id, float *Y,
+                       double *stats, int64_t rows, int in, int out, void *stream) {
     if (!A || !W || !bias || !Y || rows < 0 || in < 1 || out < 1) return DDG_E_ARG;
     if (A2 ? (in1 < 1 || in1 >= in) : (in1 != in)) return DDG_E_ARG;
     if ((prologue == DDG_PRO_ADD_EMB || prologue == DDG_PRO_EMB_RELU) && !emb) return DDG_E_ARG;
@@ -474,9 +475,19 @@ extern "C" int ddg_linear(const float *A, const float *A2, int in1, const float 
     if (rows == 0) return DDG_OK;
     LinArgs p;
     p.A = A; p.A2 = A2; p.in1 = in1; p.W = W; p.bias = bias; p.emb = emb; p.t = t; p.t_uniform = t_uniform;
+    p.emb_rows = emb_rows < 1 ? 1 : emb_rows;
     p.scale = scale; p.shift = shift; p.drop = drop; p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
     p.Y = Y; p.stats = stats; p.rows = rows; p.in = in; p.out = out;
     return launch_linear(p, prologue, (hipStream_t)stream);
+}
+
+// the generic entry point does not know how many rows emb has: the caller guarantees 0 <= t < n_steps
+extern "C" int ddg_linear(const float *A, const float *A2, int in1, const float *W, const float *bias, int prologue,
+                          const float *emb, const int64_t *t, int t_uniform, const float *scale, const float *shift,
+                          const uint8_t *drop, float drop_p, uint64_t seed, uint64_t stream_id, float *Y,
+                          double *stats, int64_t rows, int in, int out, void *stream) {
+    return linear_impl(A, A2, in1, W, bias, prologue, emb, 0x7fffffff, t, t_uniform, scale, shift, drop, drop_p, seed,
+                       stream_id, Y, stats, rows, in, out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,7 +525,7 @@ extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, cons
     if (hipMemsetAsync(st[0], 0, 3 * align256(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
     int rc;
     // layer 1: (x + temb[t]) W1^T + b1
-    rc = ddg_linear(x_t, nullptr, D, w->W1, w->b1, DDG_PRO_ADD_EMB, w->temb, t, t_uniform, nullptr, nullptr, nullptr,
+    rc = linear_impl(x_t, nullptr, D, w->W1, w->b1, DDG_PRO_ADD_EMB, w->temb, w->n_steps, t, t_uniform, nullptr, nullptr, nullptr,
                     0.f, 0, 0, z1, st[0], rows, D, E, stream);
     if (rc) return rc;
     rc = ddg_bn_finalize(st[0], w->g1, w->be1, (double)rows, bn_eps, sc[0], sh[0], E, stream);
@@ -623,13 +634,13 @@ extern "C" int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const 
     rc = ddg_linear(xtj1, xt, I / 2, w->W1, w->b1, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0,
                     0, h1, nullptr, rows, I, L, stream);
     if (rc) return rc;
-    rc = ddg_linear(h1, nullptr, L, w->W2, w->b2, DDG_PRO_EMB_RELU, w->e1, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
+    rc = linear_impl(h1, nullptr, L, w->W2, w->b2, DDG_PRO_EMB_RELU, w->e1, w->n_steps, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
                     0, 0, h2, nullptr, rows, L, L, stream);
     if (rc) return rc;
-    rc = ddg_linear(h2, nullptr, L, w->W3, w->b3, DDG_PRO_EMB_RELU, w->e2, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
+    rc = linear_impl(h2, nullptr, L, w->W3, w->b3, DDG_PRO_EMB_RELU, w->e2, w->n_steps, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
                     0, 0, h1, nullptr, rows, L, L, stream);
     if (rc) return rc;
-    rc = ddg_linear(h1, nullptr, L, w->W4, w->b4, DDG_PRO_EMB_RELU, w->e3, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
+    rc = linear_impl(h1, nullptr, L, w->W4, w->b4, DDG_PRO_EMB_RELU, w->e3, w->n_steps, t, t_uniform, nullptr, nullptr, nullptr, 0.f,
                     0, 0, out, nullptr, rows, L, O, stream);
     if (rc) return rc;
     const int64_t n = rows * O;

@@ -96,12 +96,13 @@ __global__ void k_emb_grad(const float *__restrict__ X, int64_t ldx, const int64
 }
 
 // h0 = x_t + temb[t]
+// (timesteps outside the embedding table are clamped in every kernel below: torch would raise)
 __global__ void k_add_emb(const float *__restrict__ x, const float *__restrict__ emb, const int64_t *__restrict__ t,
-                          int rows, int D, float *__restrict__ out) {
+                          int n_steps, int rows, int D, float *__restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * D) return;
     const int r = e / D, k = e - r * D;
-    out[e] = x[e] + emb[(int64_t)t[r] * D + k];
+    out[e] = x[e] + emb[(int64_t)min(max((int)t[r], 0), n_steps - 1) * D + k];
 }
 
 // BatchNorm(train) + ReLU + Dropout, forward, with the gate (0 or 1/(1-p) where the unit is on) saved
@@ -213,11 +214,12 @@ __global__ void k_res_ngood(const float *__restrict__ M, const int32_t *__restri
 
 // discriminator hidden activation r = relu(a + e[t]) and its backward
 __global__ void k_emb_relu_fwd(const float *__restrict__ a, const float *__restrict__ emb,
-                               const int64_t *__restrict__ t, int rows, int width, float *__restrict__ r_out) {
+                               const int64_t *__restrict__ t, int n_steps, int rows, int width,
+                               float *__restrict__ r_out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * width) return;
     const int r = e / width, k = e - r * width;
-    r_out[e] = fmaxf(a[e] + emb[(int64_t)t[r] * width + k], 0.f);
+    r_out[e] = fmaxf(a[e] + emb[(int64_t)min(max((int)t[r], 0), n_steps - 1) * width + k], 0.f);
 }
 __global__ void k_relu_bwd(const float *__restrict__ dr, const float *__restrict__ r_act, int n,
                            float *__restrict__ da) {
@@ -235,7 +237,7 @@ __global__ void k_xtj1_train(const float *__restrict__ pred, const float *__rest
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * D) return;
     const int r = e / D;
-    const int ti = (int)t[r];
+    const int ti = min(max((int)t[r], 2), T);
     const float *betas = sched, *sa = sched + 2 * T, *ac = sched + 5 * T, *sac = sched + 6 * T, *s1m = sched + 7 * T;
     const float o = sac[ti - 2] * x0[e] + s1m[ti - 2] * eps[e];
     const float one_m = 1.f - ac[ti - 2];
@@ -348,7 +350,7 @@ __global__ void k_head_bwd(const float *__restrict__ dres, float w_res, const fl
     if (w >= rows * C) return;
     const int r = w / C, f = w - r * C;
     const int a = offsets[f], b = offsets[f + 1];
-    const int ti = (int)t[r];
+    const int ti = min(max((int)t[r], 2), T);
     const float coef = sched[6 * T + ti - 2] * sched[ti - 1] / (1.f - sched[5 * T + ti - 1]);
     const float *p = pred + (int64_t)r * D;
     auto dp = [&](int j) {
@@ -511,7 +513,7 @@ static int gen_forward_saved(const ddg_gen_weights *w, const ddg_train_batch *b,
     int rc = ddg_forward_noise(b->x0, b->eps, b->t, 0, sched, T, b->seed, b->stream_id * 8 + 7, ws.xt,
                                b->eps ? nullptr : ws.dres /* on-chip eps kept for the x_{t-1} build */, B, D, stream);
     if (rc) return rc;
-    k_add_emb<<<g256((int64_t)B * D), 256, 0, s>>>(ws.xt, w->temb, b->t, B, D, ws.h0);
+    k_add_emb<<<g256((int64_t)B * D), 256, 0, s>>>(ws.xt, w->temb, b->t, w->n_steps, B, D, ws.h0);
     const size_t mx = (size_t)(E > L ? E : L);
     if (hipMemsetAsync(ws.st[0], 0, 3 * tal(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
     const float *Wl[3] = {w->W1, w->W2, w->W3}, *bl[3] = {w->b1, w->b2, w->b3};
@@ -549,15 +551,15 @@ static int disc_forward_saved(const ddg_disc_weights *dw, const ddg_train_batch 
     int rc = ddg_linear(ws.xtj1, ws.xt, D, dw->W1, dw->b1, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
                         0.f, 0, 0, ws.a1, nullptr, B, 2 * D, H, stream);
     if (rc) return rc;
-    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a1, dw->e1, b->t, B, H, ws.r1);
+    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a1, dw->e1, b->t, dw->n_steps, B, H, ws.r1);
     rc = ddg_linear(ws.r1, nullptr, H, dw->W2, dw->b2, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
                     0, 0, ws.a2, nullptr, B, H, H, stream);
     if (rc) return rc;
-    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a2, dw->e2, b->t, B, H, ws.r2);
+    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a2, dw->e2, b->t, dw->n_steps, B, H, ws.r2);
     rc = ddg_linear(ws.r2, nullptr, H, dw->W3, dw->b3, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
                     0, 0, ws.a3, nullptr, B, H, H, stream);
     if (rc) return rc;
-    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a3, dw->e3, b->t, B, H, ws.r3);
+    k_emb_relu_fwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.a3, dw->e3, b->t, dw->n_steps, B, H, ws.r3);
     rc = ddg_linear(ws.r3, nullptr, H, dw->W4, dw->b4, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f,
                     0, 0, ws.a4, nullptr, B, H, C, stream);
     if (rc) return rc;

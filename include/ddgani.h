@@ -119,7 +119,9 @@ int ddg_mask_merge(const float *x, const float *M, const float *xhat, const int3
  * A2 == NULL -> in1 must equal in.
  * drop: uint8[rows,in] keep-mask (1 = keep, scaled by 1/(1-p)) or NULL; when NULL and
  * drop_p > 0 the mask is generated on chip (Philox, seed/stream_id); drop_p == 0 -> none.
- * t: int64[rows] or NULL (t_uniform).  emb: [n_steps,in].
+ * t: int64[rows] or NULL (t_uniform).  emb: [n_steps,in]; ddg_linear cannot know n_steps: its caller guarantees
+ * 0 <= t < n_steps.  The composed entry points (ddg_denoiser_fwd, ddg_disc_fwd, the training steps,
+ * ddg_forward_noise) clamp a timestep outside its table instead of reading past it (torch would raise).
  * stats (optional, may be NULL): double[2*out]; the kernel ADDS column sums of Y and Y^2
  * (fp64) into it (zero it first; multi-GPU callers all-reduce it before ddg_bn_finalize).
  * ------------------------------------------------------------------------------------- */
