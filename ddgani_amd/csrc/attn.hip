@@ -34,17 +34,20 @@
 #define TK 32            // keys per tile
 #define HBINS 128
 #define HSTRIDE 129
-#define WHSTRIDE 131     // window passes: [0] below the bracket, [1 .. HBINS] its bins, [HBINS + 1] above
+// window passes: counter row of a query = [0] below the bracket, [1 .. WBINS] its bins, [WBINS + 1] above.  59 bins: the
+// rows of a workgroup (30.5 KB) and the two key tiles (49 KB at DP = 192) leave room for two workgroups per CU
+#define WBINS 59
+#define WHSTRIDE 61
 
 enum { MODE_TOPK = 0, MODE_HIST = 1, MODE_FILL = 2, MODE_WIN = 3, MODE_WFILL = 4 };
 // Window selection for k > DDG_MAX_TOPK_REG (run_window_select / run_window_fill below): the k-th largest logit of
-// a pair is bracketed on a strided SAMPLE of its keys (three cheap passes), the bracket is resolved to one of 128
+// a pair is bracketed on a strided SAMPLE of its keys (three cheap passes), the bracket is resolved to one of 59
 // bins by ONE full pass that also counts what lies above it, and the second full pass accumulates everything
 // above that bin while listing the bin's own keys (<= WIN_CAP) for an exact in-list selection (k_attn_wlist).
 // Two full similarity passes instead of the radix path's six; pairs whose bracket misses go through the radix path.
 enum { WIN_MINMAX = 0, WIN_SHIST = 1, WIN_FULL = 2 };
 #define WIN_SAMPLE 8192      // sampled keys per column (stride = nk / WIN_SAMPLE)
-#define WIN_CAP 512          // listed keys per pair
+#define WIN_CAP 1024         // listed keys per pair
 #define WIN_GROUP 4096       // workgroups per launch group of the second full pass (bounds the lists)
 #define WIN_SIGMAS 6.f       // half width of the sample bracket in standard deviations of the sample rank
 #define ATTN_WINDOW 100      // internal selector of run_select (not a public mode)
@@ -88,7 +91,7 @@ struct AttnArgs {
     int level;                 // radix level (MODE_HIST)
     int dcs;                   // LDS accumulator stride (MODE_FILL)
     // window selection (k > DDG_MAX_TOPK_REG)
-    float *wlo, *ww;           // [slots] lower edge and bin width of the pair's current bracket (128 bins)
+    float *wlo, *ww;           // [slots] lower edge and bin width of the pair's current bracket (WBINS bins)
     int32_t *wst;              // [slots] WST_* bits | selected bin << 8
     int32_t *nab;              // [slots] sample passes: sampled logits above the bracket; after MODE_WFILL: listed keys
     float *zab;                // [slots] MODE_WFILL: sum of the weights above the selected bin
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     }
     // window passes: tt = fma(v, winv, nwl) is the bin coordinate of a logit inside the pair's bracket (the same
     // expression in both full passes, so a logit falls into the same bin in both)
-    float winv = 0.f, nwl = 0.f, smin = INFINITY, fb = INFINITY, fb1 = INFINITY;
+    float winv = 0.f, nwl = 0.f, smin = INFINITY, fb = INFINITY, fb1 = INFINITY, nsmax2 = 0.f, kinv = 1.f;
     float accr[8];
     int wst = 0;
     if (MODE == MODE_WIN) {
@@ -361,13 +364,15 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         nwl = -p.wlo[slot] * winv;
         wst = p.wst[slot];
         smax = p.smax[slot];
+        nsmax2 = -smax * 1.44269504088896340736f;
+        if (SPLIT) kinv = 1.f / p.kscale[0];
         active = qrow >= 0 && p.flag[slot] == 0;
         if (active) {
             // selected bin b: logits with tt >= b + 1 lie above it, b <= tt < b + 1 inside.  A bracket without an upper
             // (lower) edge counted everything above (below) it into bin 127 (0).  WST_ALL: nwl = +inf, all kept.
             const int b = wst >> 8;
             fb = ((wst & WST_OPENBOT) && b == 0) ? -INFINITY : (float)b;
-            fb1 = ((wst & WST_OPENTOP) && b == HBINS - 1) ? INFINITY : (float)(b + 1);
+            fb1 = ((wst & WST_OPENTOP) && b == WBINS - 1) ? INFINITY : (float)(b + 1);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) accr[e] = 0.f;
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     // ---- key streaming
     const int st_row = tid >> 3, st_c = tid & 7;
     f32x4 pf[NPF];
+    bool pfx_ok = false;
     float pfx = 0.f;                       // SPLIT + MODE_WFILL: fp32 value st_c of the key row's column block (side tile)
     float *xs0 = extra + QPB, *xs1 = extra + QPB + 256;
     const float *ksrc = SPLIT ? reinterpret_cast<const float *>(p.Xks) : p.Xkp;     // rows of DP * 4 bytes either way
@@ -393,16 +399,19 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         const float *src = ksrc + (int64_t)(kidx < 0 ? 0 : kidx) * DP + st_c * 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            pf[i] = *reinterpret_cast<const f32x4 *>(src + 32 * i);
-            if (kidx < 0) pf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (SPLIT && MODE == MODE_WFILL) pfx = (kidx >= 0 && st_c < d_c) ? p.Xkp[(int64_t)kidx * DP + off_c + st_c] : 0.f;
+            pf[i] = *reinterpret_cast<const f32x4 *>(src + 32 * i);      // rows past the list: zeroed at commit time, so that
+        }                                                                //   nothing waits for the loads here
+#ifndef EXP_NOPFX
+        pfx_ok = kidx >= 0;
+        // unconditional load (clamped address): a predicated one makes the compiler wait for it right here
+        if (SPLIT && MODE == MODE_WFILL) pfx = p.Xkp[(int64_t)(kidx < 0 ? 0 : kidx) * DP + off_c + (st_c < d_c ? st_c : 0)];
+#endif
     };
     auto commit = [&](float *buf) {
         float *dst = buf + st_row * LSTR + st_c * 4;
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) *reinterpret_cast<f32x4 *>(dst + 32 * i) = pf[i];
-        if (SPLIT && MODE == MODE_WFILL) (buf == kbuf0 ? xs0 : xs1)[tid] = pfx;
+        for (int i = 0; i < NPF; ++i) *reinterpret_cast<f32x4 *>(dst + 32 * i) = pfx_ok ? pf[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (SPLIT && MODE == MODE_WFILL) (buf == kbuf0 ? xs0 : xs1)[tid] = (pfx_ok && st_c < d_c) ? pfx : 0.f;
     };
 
     const int ntk = (nk + TK - 1) / TK;
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         const bool full = rem >= TK;
 
 #ifdef EXP_NOEPI       // timing experiments only (wrong results): no per-logit work
-        if (MODE == MODE_WIN || MODE == MODE_WFILL) {
+        if (MODE == EXP_NOEPI) {
             smax = fmaxf(smax, acc[0] + acc[5] + acc[15]);
         } else
 #endif
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             }
         } else if (MODE == MODE_WIN) {
             // branch-free: every logit adds one to a counter of its query's row -- [0] below the bracket, [1 + bin],
-            // [1 + HBINS] above it (rows of the last tile past the key list count as "below": taken out at the end)
+            // [1 + WBINS] above it (rows of the last tile past the key list count as "below": taken out at the end)
             uint32_t *hist = reinterpret_cast<uint32_t *>(extra) + (wid * 32 + r32) * WHSTRIDE;
             if (!full) {
 #pragma unroll
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                     const float v = acc[g];
                     if (p.level == WIN_FULL) smax = fmaxf(smax, v);
                     int idx = (int)floorf(fmaf(v, winv, nwl));
-                    idx = min(max(idx, -1), HBINS) + 1;
+                    idx = min(max(idx, -1), WBINS) + 1;
                     atomicAdd(&hist[idx], 1u);
                 }
             }
@@ -513,43 +522,56 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                 for (int g = 0; g < 16; ++g)
                     if ((g & 3) + 8 * (g >> 2) + 4 * h >= rem) acc[g] = NAN;           // tt = NaN: neither kept nor listed
             }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+            // The common path is straight-line code per column class (the class is workgroup-uniform): weights of all 16
+            // logits, accumulation, and ONE wave-wide test per tile whether any logit fell into the selected bin.
+            const float *xsb = SPLIT ? (cur == kbuf0 ? xs0 : xs1) : cur + off_c;    // fp32 values of the key rows' column block
+            constexpr int XSTR = SPLIT ? 8 : LSTR;
+            unsigned inbm = 0;
+            auto weight = [&](int g) {
                 const float v = acc[g];
                 const float tt = fmaf(v, winv, nwl);
                 const bool keep = tt >= fb1;
-                const float w = keep ? __builtin_amdgcn_exp2f((v - smax) * 1.44269504088896340736f) : 0.f;
+                const float w = keep ? __builtin_amdgcn_exp2f(fmaf(v, 1.44269504088896340736f, nsmax2)) : 0.f;
                 Z += w;
-                // fp32 values of the key row's column block: from the tile itself, or (SPLIT) from the side tile /
-                // for blocks wider than it, rebuilt from the two halves
-                const float *xr = SPLIT ? (cur == kbuf0 ? xs0 : xs1) + kr * 8 : cur + kr * LSTR + off_c;
-                if (d_c == 1) {
-                    accr[0] += w * xr[0];
-                } else if (d_c <= 8) {
+                inbm |= (tt >= fb && !keep) ? (1u << g) : 0u;
+                return w;
+            };
+            if (d_c == 1) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) accr[e] += w * xr[e];      // e >= d_c: finite neighbours / zeros, never read back
-                } else {
-                    float *accb = extra + QPB + XOFF + (int64_t)tid * p.dcs;
-                    if (__any(keep)) {
-                        if constexpr (SPLIT) {
+                for (int g = 0; g < 16; ++g) {
+                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                    accr[0] += weight(g) * xsb[kr * XSTR];
+                }
+            } else {
+                float *accb = extra + QPB + XOFF + (int64_t)tid * p.dcs;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                    const float w = weight(g);
+                    if (d_c <= 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) accr[e] += w * xsb[kr * XSTR + e];   // e >= d_c: zeros / finite neighbours, never read back
+                    } else if (__any(w != 0.f)) {
+                        if constexpr (SPLIT) {       // blocks wider than the side tile: rebuilt from the two halves
                             const _Float16 *hr = reinterpret_cast<const _Float16 *>(cur + kr * LSTR) + off_c;
-                            const float kinv = 1.f / p.kscale[0];
                             for (int e = 0; e < d_c; ++e)
                                 accb[e] += w * (((float)hr[e] + (float)hr[DP + e] * 0x1p-11f) * kinv);
                         } else {
-                            for (int e = 0; e < d_c; ++e) accb[e] += w * xr[e];
+                            for (int e = 0; e < d_c; ++e) accb[e] += w * xsb[kr * XSTR + e];
                         }
                     }
                 }
-                const bool inb = tt >= fb && !keep;
-                if (__any(inb)) {
-                    if (inb) {                                              // inside the selected bin: listed for k_attn_wlist
+            }
+            if (__any(inbm != 0)) {                  // rare: keys inside the selected bin are listed for k_attn_wlist
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    if (inbm & (1u << g)) {
+                        const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
                         const int i = atomicAdd(&lcur[wid * 32 + r32], 1);
                         if (i < p.wcap) {
                             const int64_t o = (((int64_t)blockIdx.x * QPB) + wid * 32 + r32) * p.wcap + i;
                             p.lpos[o] = t * TK + kr;
-                            p.lval[o] = v;
+                            p.lval[o] = acc[g];
                         }
                     }
                 }
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                 // the whole sampled range as the first bracket; nk_all < k keeps every key (wlo = -inf puts them all above)
                 const bool all = nk_all < p.k;
                 p.wlo[slot] = all ? -INFINITY : smin;
-                p.ww[slot] = all ? 1.f : fmaxf((smax - smin) * (1.f / HBINS), 1e-30f);
+                p.ww[slot] = all ? 1.f : fmaxf((smax - smin) * (1.f / WBINS), 1e-30f);
                 p.wst[slot] = all ? WST_ALL : 0;
                 p.flag[slot] = 0;
                 p.rank[slot] = 0;
@@ -605,7 +627,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                 const int st = p.wst[sl];
                 if (!(st & WST_ALL) && p.qlist[sl] >= 0) {
                     const float lo = p.wlo[sl], w = p.ww[sl];
-                    const int below = (int)hrow[0] - (ntk * TK - nk), above = (int)hrow[1 + HBINS];
+                    const int below = (int)hrow[0] - (ntk * TK - nk), above = (int)hrow[1 + WBINS];
                     if (p.level == WIN_SHIST) {
                         // sample ranks that bracket the population's k-th largest with WIN_SIGMAS of slack
                         const float q = (float)p.k / (float)nk_all;
@@ -613,7 +635,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                         const float gs = WIN_SIGMAS * sqrtf((float)nk * q * (1.f - q)) + 3.f;
                         const int tgt_hi = (int)floorf(rs - gs);     // at most this many sampled logits above the bracket
                         const int tgt_lo = (int)ceilf(rs + gs);      // at least this many at or above its lower edge
-                        int nst = st, ab = above, b_hi = HBINS - 1;
+                        int nst = st, ab = above, b_hi = WBINS - 1;
                         if ((st & WST_OPENTOP) || tgt_hi < ab) {
                             nst |= WST_OPENTOP;
                         } else {
@@ -626,7 +648,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                         }
                         if ((st & WST_OPENBOT) || cum < tgt_lo) nst |= WST_OPENBOT;
                         p.wlo[sl] = lo + (float)b_lo * w;
-                        p.ww[sl] = fmaxf((float)(b_hi - b_lo + 1) * w * (1.f / HBINS), 1e-30f);
+                        p.ww[sl] = fmaxf((float)(b_hi - b_lo + 1) * w * (1.f / WBINS), 1e-30f);
                         p.wst[sl] = nst;
                     } else {
                         // the bin of the k-th largest logit and its rank inside the bin; a bracket without an upper
@@ -634,11 +656,11 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                         const int top_extra = (st & WST_OPENTOP) ? above : 0;
                         const int bot_extra = (st & WST_OPENBOT) ? below : 0;
                         const int r = p.k - ((st & WST_OPENTOP) ? 0 : above);
-                        int cum = 0, b = HBINS - 1, cnt = 0;
+                        int cum = 0, b = WBINS - 1, cnt = 0;
                         bool found = false;
                         if (r > 0) {
                             for (; b >= 0; --b) {
-                                cnt = (int)hq[b] + (b == HBINS - 1 ? top_extra : 0) + (b == 0 ? bot_extra : 0);
+                                cnt = (int)hq[b] + (b == WBINS - 1 ? top_extra : 0) + (b == 0 ? bot_extra : 0);
                                 if (cum + cnt >= r) { found = true; break; }
                                 cum += cnt;
                             }
