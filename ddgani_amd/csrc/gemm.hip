@@ -414,7 +414,95 @@ static bool linear_force_f32() {
     return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The plain layer Y = [A | A2] W^T + b for a few rows (the B = 128 training steps): a 128-row tile would occupy two or
+// three CUs and walk the whole depth as one dependent chain of global loads (20-67 us per layer).  Here a workgroup owns
+// a 32 x 32 tile of Y and its four waves a quarter of the depth each (fp32 MFMA, 16-byte operand loads when the widths
+// allow); the partial tiles meet in LDS and are added in a fixed order, so the result does not depend on timing.
+// fp64 column sums of y and y^2 (BatchNorm statistics) as in k_linear: one atomicAdd per column and row tile.
+// ---------------------------------------------------------------------------------------------
+#define SMALL_MAX_ROWS 256
+__global__ __launch_bounds__(256) void k_linear_small(LinArgs p) {
+    __shared__ float red[4][32 * 33];
+    __shared__ double sred[2][8][32];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int m = m0 + r32, n = n0 + r32;
+    const bool mok = m < p.rows, nok = n < p.out;
+    const int K = p.in, in2 = p.in - p.in1;
+    // depth slice of this wave, a multiple of 8
+    const int kper = ((K + 31) / 32) * 8;
+    const int k0 = wid * kper, k1 = min(K, k0 + kper);
+    const float *Wr = p.W + (int64_t)(nok ? n : 0) * K;
+    const float *Ar = p.A + (int64_t)(mok ? m : 0) * p.in1;
+    const float *A2r = p.A2 ? p.A2 + (int64_t)(mok ? m : 0) * in2 : nullptr;
+    auto a_at = [&](int k) { return k < p.in1 ? Ar[k] : A2r[k - p.in1]; };
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    const bool vec = ((K | p.in1) & 3) == 0 && ((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.A2)) & 15) == 0;
+    int k = k0;
+    if (vec) {
+        // lane half h takes depth positions k + 4h .. k + 4h + 3 of an 8-deep step (the same permutation on both operands)
+        for (; k + 8 <= k1; k += 8) {
+            const int kk = k + 4 * h;
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(kk < p.in1 ? Ar + kk : A2r + (kk - p.in1));
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wr + kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mok ? a4[j] : 0.f, nok ? w4[j] : 0.f, acc, 0, 0, 0);
+        }
+    }
+    for (; k < k1; k += 2) {
+        const int kk = k + h;
+        const float a = (mok && kk < k1) ? a_at(kk) : 0.f;
+        const float w = (nok && kk < k1) ? Wr[kk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) red[wid][((g & 3) + 8 * (g >> 2) + 4 * h) * 33 + r32] = acc[g];
+    __syncthreads();
+    // thread -> column tid & 31, rows 4 (tid >> 5) .. + 3 of the tile
+    const int c = tid & 31, rg = tid >> 5;
+    const int col = n0 + c;
+    const float bias = col < p.out ? p.bias[col] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = rg * 4 + i;
+        const int row = m0 + rl;
+        const float y = ((red[0][rl * 33 + c] + red[1][rl * 33 + c]) + (red[2][rl * 33 + c] + red[3][rl * 33 + c])) + bias;
+        if (row < p.rows && col < p.out) {
+            p.Y[(int64_t)row * p.out + col] = y;
+            s1 += (double)y;
+            s2 += (double)y * (double)y;
+        }
+    }
+    if (p.stats) {
+        sred[0][rg][c] = s1;
+        sred[1][rg][c] = s2;
+        __syncthreads();
+        if (tid < 64) {
+            const int which = tid >> 5;
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += sred[which][j][c];
+            if (col < p.out) atomicAdd(&p.stats[which * p.out + col], t);
+        }
+    }
+}
+
 static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
+    if (prologue == DDG_PRO_NONE && p.rows <= SMALL_MAX_ROWS && !p.drop && p.drop_p == 0.f) {
+        static const bool big = [] { const char *e = getenv("DDG_LINEAR_TILE128"); return e && e[0] == '1'; }();
+        if (!big) {
+            dim3 g((unsigned)((p.out + 31) / 32), (unsigned)((p.rows + 31) / 32));
+            k_linear_small<<<g, 256, 0, s>>>(p);
+            DDG_CHECK_LAUNCH();
+            return DDG_OK;
+        }
+    }
     const int64_t ntiles = ceil_div64(p.rows, BM);
     const int ncol = (p.out + BN - 1) / BN;
     int64_t gx = ntiles;

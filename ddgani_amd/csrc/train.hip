@@ -74,28 +74,47 @@ static int gemm_dW(const float *dY, const float *H, float *dW, int rows, int in,
     return gemm_small(dY, 1, out, H, in, 1, dW, in, out, in, rows, s);
 }
 
+// Column reductions over the B rows of a minibatch: a workgroup owns 32 columns, its 8 row slices (rows slice, slice + 8,
+// ...) run in parallel and meet in LDS in a fixed order -- one thread per column walking all rows was a dependent chain
+// of B loads (12-55 us per kernel at B = 128).
+#define CR_SLICES 8
+__device__ __forceinline__ float colred8(float v, float (*red)[32], int slice, int c) {
+    red[slice][c] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < CR_SLICES; ++j) t += red[j][c];
+    __syncthreads();
+    return t;
+}
+static inline unsigned gcol32(int n) { return (unsigned)((n + 31) / 32); }
+
 // out[col] = sum_r X[r,col]                                  (bias gradients)
-__global__ void k_colsum(const float *__restrict__ X, int rows, int N, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ X, int rows, int N, float *__restrict__ out) {
+    __shared__ float red[CR_SLICES][32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += X[(int64_t)r * N + c];
-    out[c] = s;
+    if (col < N)
+        for (int r = slice; r < rows; r += CR_SLICES) s += X[(int64_t)r * N + col];
+    s = colred8(s, red, slice, c);
+    if (slice == 0 && col < N) out[col] = s;
 }
 
-// out[s,col] = sum over rows r with t[r] == s of X[r, col]   (embedding gradients, dense like torch's)
-__global__ void k_emb_grad(const float *__restrict__ X, int64_t ldx, const int64_t *__restrict__ t, int rows, int N,
-                           int n_steps, float *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_steps * N) return;
-    const int s = e / N, c = e - s * N;
+// out[s,col] = sum over rows r with t[r] == s of X[r, col]   (embedding gradients, dense like torch's); grid (cols/32, n_steps)
+__global__ __launch_bounds__(256) void k_emb_grad(const float *__restrict__ X, int64_t ldx, const int64_t *__restrict__ t,
+                                                  int rows, int N, int n_steps, float *__restrict__ out) {
+    __shared__ float red[CR_SLICES][32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c, st = blockIdx.y;
     float a = 0.f;
-    for (int r = 0; r < rows; ++r)
-        if ((int)t[r] == s) a += X[(int64_t)r * ldx + c];
-    out[e] = a;
+    if (col < N)
+        for (int r = slice; r < rows; r += CR_SLICES)
+            if ((int)t[r] == st) a += X[(int64_t)r * ldx + col];
+    a = colred8(a, red, slice, c);
+    if (slice == 0 && col < N) out[(int64_t)st * N + col] = a;
 }
 
-// h0 = x_t + temb[t]
 // (timesteps outside the embedding table are clamped in every kernel below: torch would raise)
 __global__ void k_add_emb(const float *__restrict__ x, const float *__restrict__ emb, const int64_t *__restrict__ t,
                           int n_steps, int rows, int D, float *__restrict__ out) {
@@ -126,30 +145,40 @@ __global__ void k_bn_act_fwd(const float *__restrict__ z, const float *__restric
     gate[e] = g;
 }
 
-// backward of the above for one layer; one thread per column.
+// backward of the above for one layer; 32 columns x 8 row slices per workgroup (see colred8).
 //   da = dh * gate ; dbeta = sum da ; dgamma = sum da * xhat ; dz = gamma*invstd*(da - dbeta/B - xhat*dgamma/B)
-__global__ void k_bn_act_bwd(const float *__restrict__ dh, const float *__restrict__ gate, const float *__restrict__ z,
-                             const double *__restrict__ stats, const float *__restrict__ gamma, float eps, int rows,
-                             int width, float *__restrict__ dz, float *__restrict__ dgamma,
-                             float *__restrict__ dbeta) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= width) return;
-    const double mean_d = stats[k] / rows;
-    double var = stats[width + k] / rows - mean_d * mean_d;
+__global__ __launch_bounds__(256) void k_bn_act_bwd(const float *__restrict__ dh, const float *__restrict__ gate,
+                                                    const float *__restrict__ z, const double *__restrict__ stats,
+                                                    const float *__restrict__ gamma, float eps, int rows, int width,
+                                                    float *__restrict__ dz, float *__restrict__ dgamma,
+                                                    float *__restrict__ dbeta) {
+    __shared__ float red[CR_SLICES][32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + c;
+    const bool ok = k < width;
+    const int kk = ok ? k : 0;
+    const double mean_d = stats[kk] / rows;
+    double var = stats[width + kk] / rows - mean_d * mean_d;
     if (var < 0) var = 0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mean = (float)mean_d;
     float sda = 0.f, sdx = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        const int64_t e = (int64_t)r * width + k;
-        const float da = dh[e] * gate[e];
-        sda += da;
-        sdx += da * ((z[e] - mean) * invstd);
+    if (ok)
+        for (int r = slice; r < rows; r += CR_SLICES) {
+            const int64_t e = (int64_t)r * width + k;
+            const float da = dh[e] * gate[e];
+            sda += da;
+            sdx += da * ((z[e] - mean) * invstd);
+        }
+    sda = colred8(sda, red, slice, c);
+    sdx = colred8(sdx, red, slice, c);
+    if (!ok) return;
+    if (slice == 0) {
+        dgamma[k] = sdx;
+        dbeta[k] = sda;
     }
-    dgamma[k] = sdx;
-    dbeta[k] = sda;
     const float gi = gamma[k] * invstd, inv_n = 1.f / (float)rows;
-    for (int r = 0; r < rows; ++r) {
+    for (int r = slice; r < rows; r += CR_SLICES) {
         const int64_t e = (int64_t)r * width + k;
         const float da = dh[e] * gate[e];
         const float xh = (z[e] - mean) * invstd;
@@ -159,27 +188,36 @@ __global__ void k_bn_act_bwd(const float *__restrict__ dh, const float *__restri
 
 // The same backward split at its batch reduction (data-parallel step: the two column sums are all-reduced between
 // the kernels).  `rows` = local rows, `rows_g` = rows of the global batch (BatchNorm statistics are global).
-__global__ void k_bn_bwd_sums(const float *__restrict__ dh, const float *__restrict__ gate, const float *__restrict__ z,
-                              const double *__restrict__ stats, float eps, int rows, double rows_g, int width,
-                              float *__restrict__ sums, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= width) return;
-    const double mean_d = stats[k] / rows_g;
-    double var = stats[width + k] / rows_g - mean_d * mean_d;
+__global__ __launch_bounds__(256) void k_bn_bwd_sums(const float *__restrict__ dh, const float *__restrict__ gate,
+                                                     const float *__restrict__ z, const double *__restrict__ stats, float eps,
+                                                     int rows, double rows_g, int width, float *__restrict__ sums,
+                                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float red[CR_SLICES][32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + c;
+    const bool ok = k < width;
+    const int kk = ok ? k : 0;
+    const double mean_d = stats[kk] / rows_g;
+    double var = stats[width + kk] / rows_g - mean_d * mean_d;
     if (var < 0) var = 0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mean = (float)mean_d;
     float sda = 0.f, sdx = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        const int64_t e = (int64_t)r * width + k;
-        const float da = dh[e] * gate[e];
-        sda += da;
-        sdx += da * ((z[e] - mean) * invstd);
+    if (ok)
+        for (int r = slice; r < rows; r += CR_SLICES) {
+            const int64_t e = (int64_t)r * width + k;
+            const float da = dh[e] * gate[e];
+            sda += da;
+            sdx += da * ((z[e] - mean) * invstd);
+        }
+    sda = colred8(sda, red, slice, c);
+    sdx = colred8(sdx, red, slice, c);
+    if (ok && slice == 0) {
+        dgamma[k] = sdx;          // this rank's share: the gradient all-reduce completes it
+        dbeta[k] = sda;
+        sums[k] = sda;
+        sums[width + k] = sdx;
     }
-    dgamma[k] = sdx;          // this rank's share: the gradient all-reduce completes it
-    dbeta[k] = sda;
-    sums[k] = sda;
-    sums[width + k] = sdx;
 }
 __global__ void k_bn_bwd_apply(const float *__restrict__ dh, const float *__restrict__ gate, const float *__restrict__ z,
                                const double *__restrict__ stats, const float *__restrict__ gamma, float eps, int rows,
@@ -258,7 +296,9 @@ __global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__r
     extern __shared__ int sh_i[];
     int *ngood = sh_i;                       // [C]
     __shared__ double lsum[2];
+    __shared__ double lpart[2][16];
     __shared__ int nfield[2];
+    double lnum = 0.0, lcat = 0.0;           // this thread's share of the two loss sums
     for (int f = threadIdx.x; f < C; f += blockDim.x) ngood[f] = 0;
     if (threadIdx.x == 0) {
         lsum[0] = lsum[1] = 0.0;
@@ -299,17 +339,30 @@ __global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__r
                 dp[j] = 2.f * d / (nel * (float)nfield[0]);
                 l += (double)d * d;
             }
-            atomicAdd(&lsum[0], l / (double)nel);
+            lnum += l / (double)nel;
         } else {
             float s = 0.f;
             for (int j = a; j < b; ++j) s += (p[j] + 1e-6f) * x[j];
             s += 1e-6f;
             for (int j = a; j < b; ++j) dp[j] = -x[j] / s / (ng * (float)nfield[1]);
-            atomicAdd(&lsum[1], -(double)logf(s) / (double)ng);
+            lcat += -(double)logf(s) / (double)ng;
         }
     }
+    // wave sums, then the waves in order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lnum += __shfl_xor(lnum, o);
+        lcat += __shfl_xor(lcat, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        lpart[0][threadIdx.x >> 6] = lnum;
+        lpart[1][threadIdx.x >> 6] = lcat;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) loss_out[0] = (float)(lsum[0] / nfield[0] + lsum[1] / nfield[1]);
+    if (threadIdx.x == 0) {
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) { lsum[0] += lpart[0][w]; lsum[1] += lpart[1][w]; }
+        loss_out[0] = (float)(lsum[0] / nfield[0] + lsum[1] / nfield[1]);
+    }
 }
 
 // discriminator output, loss and d(loss)/d(logit).  mode 0: G_d_loss_func (:504); mode 1: D_loss_func (:523)
@@ -610,13 +663,13 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
         if ((rc = dp_allreduce(dp, ws.ngood, C, 0, stream))) return rc;
         ngood = ws.ngood;
     }
-    k_res_loss_grad<<<1, 256, (size_t)C * 4, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ngood, ws.dres,
+    k_res_loss_grad<<<1, 1024, (size_t)C * 4, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ngood, ws.dres,
                                                   losses_dev);
     k_head_bwd<<<g256((int64_t)B * C), 256, 0, s>>>(ws.dres, w_res, ws.dcat, 2 * D, b->M, b->t, sched_dev, T, ws.pred,
                                                    offsets_dev, is_cat_dev, C, B, D, ws.dy);
     // layer 4
     if ((rc = gemm_dW(ws.dy, ws.h3, grads->W4, B, E, D, s))) return rc;
-    k_colsum<<<g256(D), 256, 0, s>>>(ws.dy, B, D, grads->b4);
+    k_colsum<<<gcol32(D), 256, 0, s>>>(ws.dy, B, D, grads->b4);
     if ((rc = gemm_dA(ws.dy, gw->W4, ws.dh, B, E, D, s))) return rc;
     // layers 3, 2, 1
     const float *Wl[3] = {gw->W1, gw->W2, gw->W3}, *gl[3] = {gw->g1, gw->g2, gw->g3};
@@ -627,20 +680,20 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
     const int win[3] = {D, E, L}, wout[3] = {E, L, E};
     for (int l = 2; l >= 0; --l) {
         if (dp.ar) {
-            k_bn_bwd_sums<<<(wout[l] + 63) / 64, 64, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], bn_eps, B, (double)dp.Bg,
+            k_bn_bwd_sums<<<gcol32(wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], bn_eps, B, (double)dp.Bg,
                                                              wout[l], ws.bsum, dgl[l], dbel[l]);
             if ((rc = dp_allreduce(dp, ws.bsum, 2 * wout[l], 0, stream))) return rc;
             k_bn_bwd_apply<<<g256((int64_t)B * wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B,
                                                                      (double)dp.Bg, wout[l], ws.bsum, ws.dz);
         } else {
-            k_bn_act_bwd<<<(wout[l] + 63) / 64, 64, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l],
+            k_bn_act_bwd<<<gcol32(wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l],
                                                             ws.dz, dgl[l], dbel[l]);
         }
         if ((rc = gemm_dW(ws.dz, hin[l], dWl[l], B, win[l], wout[l], s))) return rc;
-        k_colsum<<<g256(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
+        k_colsum<<<gcol32(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
         if ((rc = gemm_dA(ws.dz, Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
     }
-    k_emb_grad<<<g256((int64_t)gw->n_steps * D), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
+    k_emb_grad<<<dim3(gcol32(D), (unsigned)gw->n_steps), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
     if (pred_out &&
         hipMemcpyAsync(pred_out, ws.pred, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return DDG_E_LAUNCH;
@@ -697,26 +750,26 @@ extern "C" int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc
     k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 1, loss_scale, ws.da4, loss_dev);
     // layer 4
     if ((rc = gemm_dW(ws.da4, ws.r3, grads->W4, B, H, C, s))) return rc;
-    k_colsum<<<g256(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
+    k_colsum<<<gcol32(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
     if ((rc = gemm_dA(ws.da4, dw->W4, ws.dA, B, H, C, s))) return rc;
     // layer 3
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
-    k_emb_grad<<<g256((int64_t)dw->n_steps * H), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e3);
+    k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e3);
     if ((rc = gemm_dW(ws.dB, ws.r2, grads->W3, B, H, H, s))) return rc;
-    k_colsum<<<g256(H), 256, 0, s>>>(ws.dB, B, H, grads->b3);
+    k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b3);
     if ((rc = gemm_dA(ws.dB, dw->W3, ws.dA, B, H, H, s))) return rc;
     // layer 2
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r2, B * H, ws.dB);
-    k_emb_grad<<<g256((int64_t)dw->n_steps * H), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e2);
+    k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e2);
     if ((rc = gemm_dW(ws.dB, ws.r1, grads->W2, B, H, H, s))) return rc;
-    k_colsum<<<g256(H), 256, 0, s>>>(ws.dB, B, H, grads->b2);
+    k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b2);
     if ((rc = gemm_dA(ws.dB, dw->W2, ws.dA, B, H, H, s))) return rc;
     // layer 1: input = cat(xtj1, x_t)
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r1, B * H, ws.dB);
-    k_emb_grad<<<g256((int64_t)dw->n_steps * H), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e1);
+    k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e1);
     if ((rc = gemm_small(ws.dB, 1, H, ws.xtj1, D, 1, grads->W1, 2 * D, H, D, B, s))) return rc;
     if ((rc = gemm_small(ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B, s))) return rc;
-    k_colsum<<<g256(H), 256, 0, s>>>(ws.dB, B, H, grads->b1);
+    k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b1);
     if (pred_out &&
         hipMemcpyAsync(pred_out, ws.pred, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return DDG_E_LAUNCH;
@@ -848,11 +901,11 @@ extern "C" int ddg_fd_train_epoch(const ddg_fd_weights *w, const float *X, const
         if ((rc = fd_forward(w, ws.Xb, B, ws, stream))) return rc;
         k_fd_ce<<<g256(B), 256, 0, s>>>(ws.o, ws.Yb, B, out, (float)B, ws.dO, nullptr, nullptr);
         if ((rc = gemm_dW(ws.dO, ws.h, ws.dW3, B, in, out, s))) return rc;
-        k_colsum<<<g256(out), 256, 0, s>>>(ws.dO, B, out, ws.db3);
+        k_colsum<<<gcol32(out), 256, 0, s>>>(ws.dO, B, out, ws.db3);
         if ((rc = gemm_dA(ws.dO, w->W3, ws.dh, B, in, out, s))) return rc;
         k_relu_bwd<<<g256((int64_t)B * in), 256, 0, s>>>(ws.dh, ws.h, B * in, ws.da);
         if ((rc = gemm_dW(ws.da, ws.Xb, ws.dW1, B, in, in, s))) return rc;
-        k_colsum<<<g256(in), 256, 0, s>>>(ws.da, B, in, ws.db1);
+        k_colsum<<<gcol32(in), 256, 0, s>>>(ws.da, B, in, ws.db1);
         k_fd_sgd<<<g256((int64_t)in * in), 256, 0, s>>>(w->W1, ws.dW1, in * in, lr);
         k_fd_sgd<<<g256(in), 256, 0, s>>>(w->b1, ws.db1, in, lr);
         k_fd_sgd<<<g256((int64_t)out * in), 256, 0, s>>>(w->W3, ws.dW3, out * in, lr);

@@ -95,8 +95,11 @@ def test_end_to_end(tmp_path, tag, csv_name):
     print("scores", log, "reference", scores.tolist())
     assert len(log) == len(scores)
     print("trajectory pins (max abs weight difference)", pins)
+    # epochs 1 and 2 pin the arithmetic of a training step; by epoch 10 the fp32 summation order of the GEMMs has been
+    # amplified (the reference's own runs at different thread counts are 2e-5 apart after TWO epochs,
+    # e2e_hospital_spread.json), so that pin only guards against a gross divergence
     for nm, d in pins.items():
-        tol = 1e-7 if nm.endswith("ep1") else 1e-6 if nm.endswith("ep2") else 1e-4
+        tol = 1e-7 if nm.endswith("ep1") else 1e-6 if nm.endswith("ep2") else 5e-4
         assert d < tol, (nm, d)
     if tag == "e2e_hospital":
         # the reference's own distribution on this run (see the module docstring): mean and standard deviation per pass
