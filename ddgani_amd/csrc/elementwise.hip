@@ -354,6 +354,8 @@ static int launch_head_merge(bool merge, const float *y, const float *x, const f
     int rows_pb = 8192 / D;            // <= 32 KiB of LDS
     if (rows_pb < 1) return DDG_E_UNSUPPORTED;
     if (rows_pb > 64) rows_pb = 64;
+    // a minibatch (B = 128) would fill three workgroups: fewer rows per workgroup until about 512 of them exist
+    if (rows < (int64_t)512 * rows_pb) rows_pb = (int)(rows / 512 > 1 ? rows / 512 : 1);
     const size_t lds = (size_t)rows_pb * D * sizeof(float);
     int64_t nblk = ceil_div64(rows, rows_pb);
     int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);

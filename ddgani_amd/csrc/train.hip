@@ -124,15 +124,21 @@ __global__ void k_add_emb(const float *__restrict__ x, const float *__restrict__
     out[e] = x[e] + emb[(int64_t)min(max((int)t[r], 0), n_steps - 1) * D + k];
 }
 
-// BatchNorm(train) + ReLU + Dropout, forward, with the gate (0 or 1/(1-p) where the unit is on) saved
-__global__ void k_bn_act_fwd(const float *__restrict__ z, const float *__restrict__ scale,
-                             const float *__restrict__ shift, const uint8_t *__restrict__ drop, float drop_p,
+// BatchNorm(train) + ReLU + Dropout, forward, with the gate (0 or 1/(1-p) where the unit is on) saved.  Scale and shift
+// come straight from the fp64 column sums (k_bn_finalize's arithmetic, one launch less per layer).
+__global__ void k_bn_act_fwd(const float *__restrict__ z, const double *__restrict__ stats, double n,
+                             const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                             const uint8_t *__restrict__ drop, float drop_p,
                              uint64_t seed, uint64_t stream_id, int rows, int width, float *__restrict__ hout,
                              float *__restrict__ gate) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * width) return;
     const int k = e % width;
-    const float bn = z[e] * scale[k] + shift[k];
+    const double mean = stats[k] / n;
+    double var = stats[width + k] / n - mean * mean;
+    if (var < 0) var = 0;
+    const double sc = (double)gamma[k] * (1.0 / sqrt(var + (double)eps));
+    const float bn = z[e] * (float)sc + (float)((double)beta[k] - mean * sc);
     float g = bn > 0.f ? 1.f : 0.f;
     const float keep_scale = 1.f / (1.f - drop_p);
     if (drop) {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(const float *__restrict__ dh
                                                     const float *__restrict__ z, const double *__restrict__ stats,
                                                     const float *__restrict__ gamma, float eps, int rows, int width,
                                                     float *__restrict__ dz, float *__restrict__ dgamma,
-                                                    float *__restrict__ dbeta) {
+                                                    float *__restrict__ dbeta, float *__restrict__ dbias) {
     __shared__ float red[CR_SLICES][32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + c;
@@ -172,18 +178,23 @@ __global__ __launch_bounds__(256) void k_bn_act_bwd(const float *__restrict__ dh
         }
     sda = colred8(sda, red, slice, c);
     sdx = colred8(sdx, red, slice, c);
-    if (!ok) return;
-    if (slice == 0) {
+    if (ok && slice == 0) {
         dgamma[k] = sdx;
         dbeta[k] = sda;
     }
-    const float gi = gamma[k] * invstd, inv_n = 1.f / (float)rows;
-    for (int r = slice; r < rows; r += CR_SLICES) {
-        const int64_t e = (int64_t)r * width + k;
-        const float da = dh[e] * gate[e];
-        const float xh = (z[e] - mean) * invstd;
-        dz[e] = gi * (da - sda * inv_n - xh * sdx * inv_n);
-    }
+    const float gi = gamma[kk] * invstd, inv_n = 1.f / (float)rows;
+    float sdz = 0.f;                         // gradient of the layer's bias = column sum of dz (one launch less per layer)
+    if (ok)
+        for (int r = slice; r < rows; r += CR_SLICES) {
+            const int64_t e = (int64_t)r * width + k;
+            const float da = dh[e] * gate[e];
+            const float xh = (z[e] - mean) * invstd;
+            const float v = gi * (da - sda * inv_n - xh * sdx * inv_n);
+            dz[e] = v;
+            sdz += v;
+        }
+    sdz = colred8(sdz, red, slice, c);
+    if (ok && slice == 0) dbias[k] = sdz;
 }
 
 // The same backward split at its batch reduction (data-parallel step: the two column sums are all-reduced between
@@ -237,17 +248,22 @@ __global__ void k_bn_bwd_apply(const float *__restrict__ dh, const float *__rest
 }
 
 // rows of the local batch whose mask block of field f is all ones (res_loss_func's per-field row count)
-__global__ void k_res_ngood(const float *__restrict__ M, const int32_t *__restrict__ offsets, int C, int rows, int D,
-                            float *__restrict__ ngood) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= C) return;
-    int n = 0;
-    for (int r = 0; r < rows; ++r) {
+__global__ __launch_bounds__(256) void k_res_ngood(const float *__restrict__ M, const int32_t *__restrict__ offsets, int C,
+                                                   int rows, int D, float *__restrict__ ngood) {
+    __shared__ int s_cnt[4];
+    const int f = blockIdx.x;                 // one workgroup per field, its threads take the rows
+    const int a = offsets[f], b = offsets[f + 1];
+    int cnt = 0;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
         bool good = true;
-        for (int j = offsets[f]; j < offsets[f + 1]; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
-        n += good ? 1 : 0;
+        for (int j = a; j < b; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
+        cnt += good ? 1 : 0;
     }
-    ngood[f] = (float)n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) ngood[f] = (float)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
 }
 
 // discriminator hidden activation r = relu(a + e[t]) and its backward
@@ -287,41 +303,42 @@ __global__ void k_xtj1_train(const float *__restrict__ pred, const float *__rest
 }
 #pragma clang fp contract(on)
 
-// res_loss_func (model/Diffusion.py:452-484): value and gradient w.r.t. the prediction.  One block.
-__global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__restrict__ x0,
-                                const float *__restrict__ M, const int32_t *__restrict__ offsets,
-                                const uint8_t *__restrict__ is_cat, int C, int rows, int D,
-                                const float *__restrict__ ngood_global, float *__restrict__ dpred,
-                                float *__restrict__ loss_out) {
-    extern __shared__ int sh_i[];
-    int *ngood = sh_i;                       // [C]
-    __shared__ double lsum[2];
-    __shared__ double lpart[2][16];
-    __shared__ int nfield[2];
-    double lnum = 0.0, lcat = 0.0;           // this thread's share of the two loss sums
-    for (int f = threadIdx.x; f < C; f += blockDim.x) ngood[f] = 0;
-    if (threadIdx.x == 0) {
-        lsum[0] = lsum[1] = 0.0;
-        int nn = 0, nc = 0;
-        for (int f = 0; f < C; ++f) { if (is_cat[f]) ++nc; else ++nn; }
-        nfield[0] = nn > 0 ? nn : 1;
-        nfield[1] = nc > 0 ? nc : 1;
-    }
-    __syncthreads();
+// res_loss_func (model/Diffusion.py:452-484): value and gradient w.r.t. the prediction.  One workgroup per table field:
+// its threads take the rows, count the rows whose mask block is complete (unless the caller hands over the counts of the
+// global batch), then write the gradient and reduce the field's loss sum into lpart[f] (fixed order).  k_head_bwd, the
+// next kernel of the step, adds the fields up in field order and writes the loss value.
+__global__ __launch_bounds__(256) void k_res_loss_grad(const float *__restrict__ pred, const float *__restrict__ x0,
+                                                       const float *__restrict__ M, const int32_t *__restrict__ offsets,
+                                                       const uint8_t *__restrict__ is_cat, int C, int rows, int D,
+                                                       const float *__restrict__ ngood_global, float *__restrict__ dpred,
+                                                       double *__restrict__ lpart) {
+    __shared__ int s_cnt[4];
+    __shared__ double s_l[4];
+    const int f = blockIdx.x;
+    const int a = offsets[f], b = offsets[f + 1];
+    const bool cat = is_cat[f] != 0;
+    int nn = 0, nc = 0;
+    for (int g = 0; g < C; ++g) { if (is_cat[g]) ++nc; else ++nn; }
+    const float nfield = (float)(cat ? (nc > 0 ? nc : 1) : (nn > 0 ? nn : 1));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float ng;
     if (ngood_global) {          // data-parallel step: the counts of the GLOBAL batch (all-reduced by the caller)
-        for (int f = threadIdx.x; f < C; f += blockDim.x) ngood[f] = (int)ngood_global[f];
+        ng = ngood_global[f];
     } else {
-        for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
-            const int r = w / C, f = w - r * C;
+        int cnt = 0;
+        for (int r = threadIdx.x; r < rows; r += blockDim.x) {
             bool good = true;
-            for (int j = offsets[f]; j < offsets[f + 1]; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
-            if (good) atomicAdd(&ngood[f], 1);
+            for (int j = a; j < b; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
+            cnt += good ? 1 : 0;
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) s_cnt[wid] = cnt;
+        __syncthreads();
+        ng = (float)(s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
     }
-    __syncthreads();
-    for (int w = threadIdx.x; w < rows * C; w += blockDim.x) {
-        const int r = w / C, f = w - r * C;
-        const int a = offsets[f], b = offsets[f + 1];
+    double l = 0.0;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
         bool good = true;
         for (int j = a; j < b; ++j) good = good && (M[(int64_t)r * D + j] == 1.f);
         const float *p = pred + (int64_t)r * D, *x = x0 + (int64_t)r * D;
@@ -330,45 +347,34 @@ __global__ void k_res_loss_grad(const float *__restrict__ pred, const float *__r
             for (int j = a; j < b; ++j) dp[j] = 0.f;
             continue;
         }
-        const float ng = (float)ngood[f];
-        if (!is_cat[f]) {
+        if (!cat) {
             const float nel = ng * (float)(b - a);
-            double l = 0.0;
+            double lr = 0.0;
             for (int j = a; j < b; ++j) {
                 const float d = p[j] - x[j];
-                dp[j] = 2.f * d / (nel * (float)nfield[0]);
-                l += (double)d * d;
+                dp[j] = 2.f * d / (nel * nfield);
+                lr += (double)d * d;
             }
-            lnum += l / (double)nel;
+            l += lr / (double)nel;
         } else {
-            float s = 0.f;
-            for (int j = a; j < b; ++j) s += (p[j] + 1e-6f) * x[j];
-            s += 1e-6f;
-            for (int j = a; j < b; ++j) dp[j] = -x[j] / s / (ng * (float)nfield[1]);
-            lcat += -(double)logf(s) / (double)ng;
+            float sdot = 0.f;
+            for (int j = a; j < b; ++j) sdot += (p[j] + 1e-6f) * x[j];
+            sdot += 1e-6f;
+            for (int j = a; j < b; ++j) dp[j] = -x[j] / sdot / (ng * nfield);
+            l += -(double)logf(sdot) / (double)ng;
         }
     }
-    // wave sums, then the waves in order
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lnum += __shfl_xor(lnum, o);
-        lcat += __shfl_xor(lcat, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        lpart[0][threadIdx.x >> 6] = lnum;
-        lpart[1][threadIdx.x >> 6] = lcat;
-    }
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    if (lane == 0) s_l[wid] = l;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (unsigned w = 0; w < blockDim.x / 64; ++w) { lsum[0] += lpart[0][w]; lsum[1] += lpart[1][w]; }
-        loss_out[0] = (float)(lsum[0] / nfield[0] + lsum[1] / nfield[1]);
-    }
+    if (threadIdx.x == 0) lpart[f] = ((s_l[0] + s_l[1]) + (s_l[2] + s_l[3])) / (double)nfield;
 }
 
 // discriminator output, loss and d(loss)/d(logit).  mode 0: G_d_loss_func (:504); mode 1: D_loss_func (:523)
 __global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__restrict__ m, int n, int64_t n_norm,
                                  int mode, float scale, float *__restrict__ da4, float *__restrict__ loss_out) {
-    __shared__ double part[256];
+    __shared__ double part[1024];
     double l = 0.0;
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const float d = 1.f / (1.f + expf(-a4[e]));
@@ -385,7 +391,7 @@ __global__ void k_disc_loss_grad(const float *__restrict__ a4, const float *__re
     }
     part[threadIdx.x] = l;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
         __syncthreads();
     }
@@ -398,8 +404,14 @@ __global__ void k_head_bwd(const float *__restrict__ dres, float w_res, const fl
                            const float *__restrict__ M, const int64_t *__restrict__ t,
                            const float *__restrict__ sched, int T, const float *__restrict__ pred,
                            const int32_t *__restrict__ offsets, const uint8_t *__restrict__ is_cat, int C, int rows,
-                           int D, float *__restrict__ dy) {
+                           int D, float *__restrict__ dy, const double *__restrict__ lpart,
+                           float *__restrict__ res_loss_out) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0 && lpart) {       // res_loss value: the fields' sums of k_res_loss_grad, numeric ones first, in field order
+        double ln = 0.0, lc = 0.0;
+        for (int g = 0; g < C; ++g) { if (is_cat[g]) lc += lpart[g]; else ln += lpart[g]; }
+        res_loss_out[0] = (float)(ln + lc);
+    }
     if (w >= rows * C) return;
     const int r = w / C, f = w - r * C;
     const int a = offsets[f], b = offsets[f + 1];
@@ -495,6 +507,7 @@ struct TrainWs {
     float *sc[3], *sf[3];
     float *xtj1, *a1, *r1, *a2, *r2, *a3, *r3, *a4, *da4, *dA, *dB, *dcat;
     float *dres, *dy, *dh, *dz;
+    double *lpart;             // res_loss_func: per-field loss sums [C]
     float *bsum, *ngood;       // data-parallel step: BatchNorm backward column sums [2*max width], per-field row counts [C]
     float *fwd_ws;             // workspace of ddg_denoiser_fwd (discriminator step)
     size_t fwd_ws_bytes;
@@ -518,6 +531,7 @@ static void train_carve(TrainWs &w, char *base, int64_t B, int D, int E, int L, 
     w.a4 = f(B * C); w.da4 = f(B * C); w.dA = f(B * H); w.dB = f(B * H); w.dcat = f(B * 2 * D);
     w.dres = f(B * D); w.dy = f(B * D); w.dh = f(B * mx); w.dz = f(B * mx);
     w.bsum = f(2 * mx); w.ngood = f(C);
+    w.lpart = (double *)take((size_t)C * 8);
     w.fwd_ws_bytes = ddg_denoiser_workspace_bytes(B, D, E, L);
     w.fwd_ws = (float *)take(w.fwd_ws_bytes);
     w.total = o;
@@ -580,9 +594,7 @@ static int gen_forward_saved(const ddg_gen_weights *w, const ddg_train_batch *b,
                         nullptr, 0.f, 0, 0, zl[l], ws.st[l], B, win[l], wout[l], stream);
         if (rc) return rc;
         if ((rc = dp_allreduce(dp, ws.st[l], 2 * wout[l], 1, stream))) return rc;      // sync-BatchNorm: global sums
-        rc = ddg_bn_finalize(ws.st[l], gl[l], bel[l], (double)dp.Bg, bn_eps, ws.sc[l], ws.sf[l], wout[l], stream);
-        if (rc) return rc;
-        k_bn_act_fwd<<<g256((int64_t)B * wout[l]), 256, 0, s>>>(zl[l], ws.sc[l], ws.sf[l], dl[l], b->drop_p, b->seed,
+        k_bn_act_fwd<<<g256((int64_t)B * wout[l]), 256, 0, s>>>(zl[l], ws.st[l], (double)dp.Bg, gl[l], bel[l], bn_eps, dl[l], b->drop_p, b->seed,
                                                                b->stream_id * 4 + l, B, wout[l], hl[l], gt[l]);
         hin = hl[l];
     }
@@ -647,7 +659,7 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
     // G_D branch first (it reads the on-chip eps parked in ws.dres), then the reconstruction loss
     rc = disc_forward_saved(dw, b, ws.pred, eps, sched_dev, T, D, ws, stream);
     if (rc) return rc;
-    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 0, w_gd, ws.da4, losses_dev + 1);
+    k_disc_loss_grad<<<1, 1024, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 0, w_gd, ws.da4, losses_dev + 1);
     // input gradient of the discriminator: da4 -> r3 -> a3 -> r2 -> a2 -> r1 -> a1 -> cat(xtj1, x_t)
     if ((rc = gemm_dA(ws.da4, dw->W4, ws.dA, B, H, C, s))) return rc;
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
@@ -659,14 +671,13 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
 
     const float *ngood = nullptr;
     if (dp.ar) {                 // res_loss_func normalises per field by the row count of the GLOBAL batch
-        k_res_ngood<<<g256(C), 256, 0, s>>>(b->M, offsets_dev, C, B, D, ws.ngood);
+        k_res_ngood<<<C, 256, 0, s>>>(b->M, offsets_dev, C, B, D, ws.ngood);
         if ((rc = dp_allreduce(dp, ws.ngood, C, 0, stream))) return rc;
         ngood = ws.ngood;
     }
-    k_res_loss_grad<<<1, 1024, (size_t)C * 4, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ngood, ws.dres,
-                                                  losses_dev);
+    k_res_loss_grad<<<C, 256, 0, s>>>(ws.pred, b->x0, b->M, offsets_dev, is_cat_dev, C, B, D, ngood, ws.dres, ws.lpart);
     k_head_bwd<<<g256((int64_t)B * C), 256, 0, s>>>(ws.dres, w_res, ws.dcat, 2 * D, b->M, b->t, sched_dev, T, ws.pred,
-                                                   offsets_dev, is_cat_dev, C, B, D, ws.dy);
+                                                   offsets_dev, is_cat_dev, C, B, D, ws.dy, ws.lpart, losses_dev);
     // layer 4
     if ((rc = gemm_dW(ws.dy, ws.h3, grads->W4, B, E, D, s))) return rc;
     k_colsum<<<gcol32(D), 256, 0, s>>>(ws.dy, B, D, grads->b4);
@@ -687,10 +698,10 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
                                                                      (double)dp.Bg, wout[l], ws.bsum, ws.dz);
         } else {
             k_bn_act_bwd<<<gcol32(wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l],
-                                                            ws.dz, dgl[l], dbel[l]);
+                                                            ws.dz, dgl[l], dbel[l], dbl[l]);
         }
         if ((rc = gemm_dW(ws.dz, hin[l], dWl[l], B, win[l], wout[l], s))) return rc;
-        k_colsum<<<gcol32(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
+        if (dp.ar) k_colsum<<<gcol32(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
         if ((rc = gemm_dA(ws.dz, Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
     }
     k_emb_grad<<<dim3(gcol32(D), (unsigned)gw->n_steps), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
@@ -747,7 +758,7 @@ extern "C" int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc
     const float *eps = b->eps ? b->eps : ws.dres;
     rc = disc_forward_saved(dw, b, ws.pred, eps, sched_dev, T, D, ws, stream);
     if (rc) return rc;
-    k_disc_loss_grad<<<1, 256, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 1, loss_scale, ws.da4, loss_dev);
+    k_disc_loss_grad<<<1, 1024, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 1, loss_scale, ws.da4, loss_dev);
     // layer 4
     if ((rc = gemm_dW(ws.da4, ws.r3, grads->W4, B, H, C, s))) return rc;
     k_colsum<<<gcol32(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
