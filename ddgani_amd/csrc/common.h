@@ -37,12 +37,25 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Stream offset in device memory (ddg_set_stream_offset): every on-chip random draw uses stream_id + *g_stream_off when the
+// pointer is set.  A caller that replays a captured HIP graph -- whose kernel arguments, stream numbers included, are
+// frozen -- advances that one device word between replays and gets fresh noise.  One copy per translation unit.
+static __device__ const uint64_t *g_stream_off = nullptr;
+__device__ __forceinline__ uint64_t stream_with_offset(uint64_t stream_id) {
+    const uint64_t *p = g_stream_off;
+    return p ? stream_id + *p : stream_id;
+}
+static inline int set_stream_off_tu(const uint64_t *dev_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stream_off), &dev_ptr, sizeof(dev_ptr)) == hipSuccess ? DDG_OK : DDG_E_LAUNCH;
+}
+
 // uniform in (0,1]: never 0, so log() is finite
 __device__ __forceinline__ float u32_to_unit(uint32_t u) { return ((u >> 8) + 1) * (1.0f / 16777216.0f); }
 
 // 4 standard normals for element group `idx` of random stream `stream_id`
 __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_id, uint64_t idx) {
     uint32_t r[4];
+    stream_id = stream_with_offset(stream_id);
     philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
                   (uint32_t)seed, (uint32_t)(seed >> 32), r);
     float u0 = u32_to_unit(r[0]), u1 = u32_to_unit(r[1]), u2 = u32_to_unit(r[2]), u3 = u32_to_unit(r[3]);
@@ -58,6 +71,7 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_i
 // 4 uniforms in (0,1] for element group idx
 __device__ __forceinline__ f32x4 philox_uniform4(uint64_t seed, uint64_t stream_id, uint64_t idx) {
     uint32_t r[4];
+    stream_id = stream_with_offset(stream_id);
     philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
                   (uint32_t)seed, (uint32_t)(seed >> 32), r);
     f32x4 o;

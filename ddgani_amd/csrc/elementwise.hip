@@ -401,3 +401,15 @@ extern "C" int ddg_bn_finalize(const double *stats, const float *gamma, const fl
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// stream offset in device memory (see common.h): set in every translation unit that draws random numbers
+// ---------------------------------------------------------------------------------------------
+int ddg_tu_set_stream_off_gemm(const uint64_t *dev_ptr);
+int ddg_tu_set_stream_off_train(const uint64_t *dev_ptr);
+extern "C" int ddg_set_stream_offset(const uint64_t *dev_ptr) {
+    int rc = set_stream_off_tu(dev_ptr);
+    if (!rc) rc = ddg_tu_set_stream_off_gemm(dev_ptr);
+    if (!rc) rc = ddg_tu_set_stream_off_train(dev_ptr);
+    return rc;
+}

@@ -738,3 +738,6 @@ extern "C" int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const 
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
+
+// this translation unit's copy of the stream-offset pointer (ddg_set_stream_offset, elementwise.hip)
+int ddg_tu_set_stream_off_gemm(const uint64_t *dev_ptr) { return set_stream_off_tu(dev_ptr); }

@@ -16,23 +16,27 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
-// generic small GEMM, one wave per 32x32 tile of C:  C[m,n] = sum_k A(m,k) * B(k,n)
+// generic small GEMM, one workgroup (four waves splitting the depth) per 32x32 tile of C:  C[m,n] = sum_k A(m,k) * B(k,n)
 // with element strides (sam, sak) / (sbk, sbn), so the same kernel serves NN, NT and TN.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_gemm_small(const float *__restrict__ A, int64_t sam, int64_t sak,
-                                                    const float *__restrict__ B, int64_t sbk, int64_t sbn,
-                                                    float *__restrict__ Cm, int64_t ldc, int M, int N, int K) {
-    const int lane = threadIdx.x, r32 = lane & 31, h = lane >> 5;
+__global__ __launch_bounds__(256) void k_gemm_small(const float *__restrict__ A, int64_t sam, int64_t sak,
+                                                     const float *__restrict__ B, int64_t sbk, int64_t sbn,
+                                                     float *__restrict__ Cm, int64_t ldc, int M, int N, int K) {
+    // the four waves of a workgroup take a quarter of the depth each; the partial tiles are added in LDS in a fixed order
+    __shared__ float red[4][32 * 33];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int m = m0 + r32, n = n0 + r32;
     const bool mok = m < M, nok = n < N;
     const float *Ap = A + (int64_t)(mok ? m : 0) * sam;
     const float *Bp = B + (int64_t)(nok ? n : 0) * sbn;
+    const int kper = ((K + 7) / 8) * 2;              // a multiple of 2
+    const int kbeg = wid * kper, kend = min(K, kbeg + kper);
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-    int k = 0;
-    for (; k + 16 <= K; k += 16) {
+    int k = kbeg;
+    for (; k + 16 <= kend; k += 16) {
         float a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -43,17 +47,23 @@ __global__ __launch_bounds__(64) void k_gemm_small(const float *__restrict__ A, 
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
-    for (; k < K; k += 2) {
+    for (; k < kend; k += 2) {
         const int kk = k + h;
-        const float a = (mok && kk < K) ? Ap[(int64_t)kk * sak] : 0.f;
-        const float b = (nok && kk < K) ? Bp[(int64_t)kk * sbk] : 0.f;
+        const float a = (mok && kk < kend) ? Ap[(int64_t)kk * sak] : 0.f;
+        const float b = (nok && kk < kend) ? Bp[(int64_t)kk * sbk] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (nok) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int row = m0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-            if (row < M) Cm[(int64_t)row * ldc + n] = acc[g];
+    for (int g = 0; g < 16; ++g) red[wid][((g & 3) + 8 * (g >> 2) + 4 * h) * 33 + r32] = acc[g];
+    __syncthreads();
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    if (n0 + c < N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = rg * 4 + i;
+            if (m0 + rl < M)
+                Cm[(int64_t)(m0 + rl) * ldc + n0 + c] =
+                    (red[0][rl * 33 + c] + red[1][rl * 33 + c]) + (red[2][rl * 33 + c] + red[3][rl * 33 + c]);
         }
     }
 }
@@ -61,7 +71,7 @@ __global__ __launch_bounds__(64) void k_gemm_small(const float *__restrict__ A, 
 static int gemm_small(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *Cm,
                       int64_t ldc, int M, int N, int K, hipStream_t s) {
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
-    k_gemm_small<<<grid, 64, 0, s>>>(A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K);
+    k_gemm_small<<<grid, 256, 0, s>>>(A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
@@ -951,3 +961,6 @@ extern "C" int ddg_fd_eval(const ddg_fd_weights *w, const float *X, const int32_
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
+
+// this translation unit's copy of the stream-offset pointer (ddg_set_stream_offset, elementwise.hip)
+int ddg_tu_set_stream_off_train(const uint64_t *dev_ptr) { return set_stream_off_tu(dev_ptr); }

@@ -288,6 +288,79 @@ def _train_batch(rnd, x, M, m_data, T, device, gen_widths, rank: int = 0):
     return x0, Mb, mb, t, dict(seed=rnd.seed, stream_id=stream_of(rnd.next_stream(), KIND_EPS, rank=rank))
 
 
+class GraphedSteps:
+    """The generator and the discriminator minibatch step as HIP graphs (throughput mode, one process): a step is about
+    45 short kernels whose launches, not their run time, set the pace.  Captured once per (network, loss scale): gather of
+    the batch rows from static index / timestep buffers, the gradient entry point, and the advance of a device counter
+    that the library adds to every random-stream number (ops.set_stream_offset) -- a graph freezes kernel arguments, so
+    the streams must move in device memory.  Per step the host draws the 128 row indices and timesteps, stages them
+    through a ring of pinned buffers, replays the graph and launches Adam (its bias corrections are host scalars).
+    The first replay (counter 0) is bit-identical to the eager step with the same stream number
+    (tests/test_gpu_graph_train.py)."""
+    RING = 64
+    BASE_STREAM = stream_of(1 << 35, KIND_EPS)      # call numbers of graph replays: 2^35 + 256 n, apart from next_call()
+
+    def __init__(self, x, M, m_data, T, device, batch=128):
+        self.x, self.M, self.m = x, M, m_data
+        self.T, self.B, self.dev = T, min(batch, x.shape[0]), device
+        self.stage = torch.empty(self.RING, 2 * self.B, dtype=torch.int64).pin_memory()
+        self.stage_np = self.stage.numpy()
+        self.slot = 0
+        self.feed = torch.zeros(2 * self.B, dtype=torch.int64, device=device)       # [indices | timesteps]
+        self.feed[self.B:] = 2
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.graphs = {}
+        ops.set_stream_offset(self.counter)
+
+    def close(self):
+        ops.set_stream_offset(None)
+
+    def same_data(self, x, M, m_data, T):
+        return (x.data_ptr(), M.data_ptr(), m_data.data_ptr(), T) == (self.x.data_ptr(), self.M.data_ptr(),
+                                                                       self.m.data_ptr(), self.T)
+
+    def _body(self, fn):
+        idx, t = self.feed[:self.B], self.feed[self.B:]
+        x0, Mb, mb = self.x.index_select(0, idx), self.M.index_select(0, idx), self.m.index_select(0, idx)
+        loss = fn(x0, Mb, mb, t)
+        self.counter.add_(1 << 32)
+        return loss
+
+    def step(self, key, fn, rnd):
+        """fn(x0, Mb, mb, t) -> loss tensor, launching on the current stream with stream number BASE_STREAM."""
+        if self.slot == 0:
+            torch.cuda.current_stream().synchronize()        # the ring's copies of the last lap have run
+        row = self.stage_np[self.slot]
+        row[:self.B] = rnd.gen.choice(self.x.shape[0], self.B, replace=False, shuffle=False)
+        row[self.B:] = rnd.gen.integers(2, self.T + 1, size=self.B)
+        self.feed.copy_(self.stage[self.slot], non_blocking=True)
+        self.slot = (self.slot + 1) % self.RING
+        ent = self.graphs.get(key)
+        if ent is None:
+            first = self._body(fn)                           # eager: this step, and workspaces / caches exist before the capture
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._body(fn)
+            self.graphs[key] = (g, loss)
+            return first
+        ent[0].replay()
+        return ent[1]
+
+
+def _graph_steps(optimizer, rnd, comm, x, M, m_data, T, device, blocked=False):
+    """the GraphedSteps of this training run, or None where the eager path applies (parity mode, several ranks, FD loss,
+    DDG_TRAIN_GRAPH=0)."""
+    import os
+    if blocked or rnd.name != "chip" or (comm is not None and comm.on) or os.environ.get("DDG_TRAIN_GRAPH", "1") == "0":
+        return None
+    gs = getattr(rnd, "_graphs", None)
+    if gs is None or not gs.same_data(x, M, m_data, T):
+        if gs is not None:
+            gs.close()
+        gs = rnd._graphs = GraphedSteps(x, M, m_data, T, device)
+    return gs
+
+
 def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, loss_scaler, other_loss, epoch,
                               total_epochs, timesteps, device, field, M, m_data, loss_weight, FDs_model_list, fields,
                               zero_feed_data, rnd=None, comm=None):
@@ -303,7 +376,17 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
     total = 0.0
     losses, fd_losses = [], []
     dp = comm is not None and comm.on
+    gs = _graph_steps(optimizer, rnd, comm, x, M, m_data, timesteps, device, blocked=len(FDs_model_list) != 0)
     for _ in range(timesteps):
+        if gs is not None:
+            def g_step(x0, Mb, mb, t):
+                return ops.train_gen_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, model.layout, DS.table, timesteps,
+                                           loss_weight["Res_weight"], loss_weight["G_D_weight"], seed=rnd.seed,
+                                           stream_id=GraphedSteps.BASE_STREAM)[0]
+            l = gs.step(("G", id(optimizer), loss_weight["Res_weight"], loss_weight["G_D_weight"]), g_step, rnd)
+            optimizer.step()
+            losses.append(l.clone())
+            continue
         x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths, rank=comm.rank if dp else 0)
         if dp:
             from .. import dist as ddist
@@ -339,7 +422,17 @@ def train_one_epoch_discriminator_noise_x(generator_x0, discriminator_noise_x, D
     scale = loss_weight["D_weight"] if epoch % 100 == 0 else 1.0
     losses = []
     dp = comm is not None and comm.on
+    gs = _graph_steps(optimizer, rnd, comm, x, M, m_data, timesteps, device)
     for _ in range(timesteps):
+        if gs is not None:
+            def d_step(x0, Mb, mb, t):
+                return ops.train_disc_grads(PG, PD, optimizer.buf, x0, Mb, mb, t, generator_x0.layout, DS.table,
+                                            timesteps, loss_scale=scale, seed=rnd.seed,
+                                            stream_id=GraphedSteps.BASE_STREAM)[0]
+            l = gs.step(("D", id(optimizer), scale), d_step, rnd)
+            optimizer.step()
+            losses.append(l.clone())
+            continue
         x0, Mb, mb, t, kw = _train_batch(rnd, x, M, m_data, timesteps, device, widths, rank=comm.rank if dp else 0)
         if dp:
             from .. import dist as ddist

@@ -37,6 +37,14 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def set_stream_offset(counter: Optional[torch.Tensor]):
+    """ddg_set_stream_offset: every on-chip random draw on the current device uses stream_id + counter[0] (an int64 / uint64
+    device tensor the caller keeps alive and advances between graph replays); None switches it off."""
+    if counter is not None and (counter.dtype not in (torch.int64, torch.uint64) or counter.numel() < 1):
+        raise _lib.DdgError("stream offset: one 64-bit integer on the device")
+    check(lib().ddg_set_stream_offset(_ptr(counter)), "ddg_set_stream_offset")
+
+
 class FieldLayout:
     """Encoded-column layout of a table: column c occupies [offsets[c], offsets[c+1])."""
 

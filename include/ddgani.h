@@ -218,6 +218,14 @@ int ddg_disc_fwd(const ddg_disc_weights *w, const float *xtj1, const float *xt, 
  * eps / drop0..2 == NULL -> drawn on chip (Philox, seed/stream_id) exactly as ddg_denoiser_fwd does.
  * pred_out (optional): the generator's prediction [rows,D] of this step.
  * ------------------------------------------------------------------------------------- */
+/* Stream offset in device memory, for callers that replay a captured HIP graph (no reference counterpart: the
+ * reference draws torch.randn_like per call).  A graph freezes kernel arguments, the random-stream numbers included.
+ * With dev_ptr set (a device uint64 owned by the caller), every on-chip draw of every entry point uses
+ * stream_id + *dev_ptr, read when the kernel RUNS: advance the word between replays and the noise is fresh.
+ * Process-wide for the current device until called again (NULL = off, the default); call it outside graph capture
+ * (it copies to a device symbol).  Explicit-noise arguments (eps, z, drop masks) are not affected. */
+int ddg_set_stream_offset(const uint64_t *dev_ptr);
+
 typedef struct ddg_train_batch {
     const float *x0;            /* [rows,D] sampled rows of the encoded table (sample_x, utils/util.py:582) */
     const float *M;             /* [rows,D] expanded mask                                     */
