@@ -422,6 +422,7 @@ static bool linear_force_f32() {
 // fp64 column sums of y and y^2 (BatchNorm statistics) as in k_linear: one atomicAdd per column and row tile.
 // ---------------------------------------------------------------------------------------------
 #define SMALL_MAX_ROWS 256
+template <int PRO>
 __global__ __launch_bounds__(256) void k_linear_small(LinArgs p) {
     __shared__ float red[4][32 * 33];
     __shared__ double sred[2][8][32];
@@ -429,36 +430,40 @@ __global__ __launch_bounds__(256) void k_linear_small(LinArgs p) {
     const int r32 = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int m = m0 + r32, n = n0 + r32;
-    const bool mok = m < p.rows, nok = n < p.out;
-    const int K = p.in, in2 = p.in - p.in1;
-    // depth slice of this wave, a multiple of 8
+    const bool mok = m < p.rows;
+    const int K = p.in;
+    // depth slice of this wave, a multiple of 8; lane half h takes positions k + 4h .. k + 4h + 3 of an 8-deep step
+    // (the same permutation on both operands); the operands come through the prologue helpers of k_linear
     const int kper = ((K + 31) / 32) * 8;
-    const int k0 = wid * kper, k1 = min(K, k0 + kper);
-    const float *Wr = p.W + (int64_t)(nok ? n : 0) * K;
-    const float *Ar = p.A + (int64_t)(mok ? m : 0) * p.in1;
-    const float *A2r = p.A2 ? p.A2 + (int64_t)(mok ? m : 0) * in2 : nullptr;
-    auto a_at = [&](int k) { return k < p.in1 ? Ar[k] : A2r[k - p.in1]; };
+    const int k0 = wid * kper, k1 = min(((K + 7) / 8) * 8, k0 + kper);
+    const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
+    const float keep_scale = 1.f / (1.f - p.drop_p);
+    int trow = 0;
+    if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && mok)
+        trow = min(max(p.t ? (int)p.t[m] : p.t_uniform, 0), p.emb_rows - 1);
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-    const bool vec = ((K | p.in1) & 3) == 0 && ((((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.A2)) & 15) == 0;
-    int k = k0;
-    if (vec) {
-        // lane half h takes depth positions k + 4h .. k + 4h + 3 of an 8-deep step (the same permutation on both operands)
-        for (; k + 8 <= k1; k += 8) {
+    if (fast) {
+        for (int k = k0; k < k1; k += 8) {
             const int kk = k + 4 * h;
-            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(kk < p.in1 ? Ar + kk : A2r + (kk - p.in1));
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Wr + kk);
+            const f32x4 a4 = lin_stage_a<PRO>(p, mok ? m : p.rows, kk, trow, keep_scale, true);     // zeros past the last row
+            const f32x4 w4 = lin_stage_b(p, n, kk, true);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mok ? a4[j] : 0.f, nok ? w4[j] : 0.f, acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], w4[j], acc, 0, 0, 0);
         }
-    }
-    for (; k < k1; k += 2) {
-        const int kk = k + h;
-        const float a = (mok && kk < k1) ? a_at(kk) : 0.f;
-        const float w = (nok && kk < k1) ? Wr[kk] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc, 0, 0, 0);
+    } else {
+        // concatenated or odd-width operands: element by element, depth positions k + h in ascending order
+        const bool nok = n < p.out;
+        for (int k = k0; k < min(K, k1); k += 2) {
+            const int kk = k + h;
+            float a = 0.f, w = 0.f;
+            if (kk < K) {
+                if (mok) a = lin_transform<PRO>(p, lin_fetch_a(p, m, kk), m, kk, trow, keep_scale);
+                if (nok) w = p.W[(int64_t)n * K + kk];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int g = 0; g < 16; ++g) red[wid][((g & 3) + 8 * (g >> 2) + 4 * h) * 33 + r32] = acc[g];
@@ -494,11 +499,17 @@ __global__ __launch_bounds__(256) void k_linear_small(LinArgs p) {
 }
 
 static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
-    if (prologue == DDG_PRO_NONE && p.rows <= SMALL_MAX_ROWS && !p.drop && p.drop_p == 0.f) {
+    if (p.rows <= SMALL_MAX_ROWS) {
         static const bool big = [] { const char *e = getenv("DDG_LINEAR_TILE128"); return e && e[0] == '1'; }();
         if (!big) {
             dim3 g((unsigned)((p.out + 31) / 32), (unsigned)((p.rows + 31) / 32));
-            k_linear_small<<<g, 256, 0, s>>>(p);
+            switch (prologue) {
+                case DDG_PRO_NONE: k_linear_small<DDG_PRO_NONE><<<g, 256, 0, s>>>(p); break;
+                case DDG_PRO_ADD_EMB: k_linear_small<DDG_PRO_ADD_EMB><<<g, 256, 0, s>>>(p); break;
+                case DDG_PRO_BN_RELU: k_linear_small<DDG_PRO_BN_RELU><<<g, 256, 0, s>>>(p); break;
+                case DDG_PRO_EMB_RELU: k_linear_small<DDG_PRO_EMB_RELU><<<g, 256, 0, s>>>(p); break;
+                default: return DDG_E_ARG;
+            }
             DDG_CHECK_LAUNCH();
             return DDG_OK;
         }
