@@ -313,7 +313,18 @@ class GraphedSteps:
         ops.set_stream_offset(self.counter)
 
     def close(self):
-        ops.set_stream_offset(None)
+        """switches the stream offset off; the counter tensor must outlive every kernel that may read it"""
+        if self.counter is not None:
+            torch.cuda.current_stream().synchronize()
+            ops.set_stream_offset(None)
+            self.counter = None
+            self.graphs = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def same_data(self, x, M, m_data, T):
         return (x.data_ptr(), M.data_ptr(), m_data.data_ptr(), T) == (self.x.data_ptr(), self.M.data_ptr(),
@@ -542,4 +553,8 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
                 impute_data.columns = values
                 b_e, r_M = epoch, cur_r
     print(b_e)
+    gsteps = getattr(rnd, "_graphs", None)
+    if gsteps is not None:       # graphed training steps: the library must not keep a pointer to their counter
+        gsteps.close()
+        rnd._graphs = None
     return impute_data.values
