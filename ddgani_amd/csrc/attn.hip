@@ -904,8 +904,14 @@ __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
 __host__ __device__ constexpr int screen_stage_keys(int KS) {
     return FILT_NW != 8 ? 64 : (KS <= 4 ? 256 : KS <= 8 ? 192 : KS <= 12 ? 128 : 96);     // 96 ... 147 KB for three buffers
 }
-template <int KS>
-__global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
+// QW = query sets (32 queries each) per wave.  QW = 2: a workgroup is FILT_NW / 2 waves, every key fragment read from LDS
+// feeds two MFMAs (one per set): one ds_read_b128 per v_mfma_f32_32x32x16_bf16 is exactly the LDS peak of a CU, so with
+// QW = 1 the matrix pipe cannot pass ~85 %.  The per-pair arrays are indexed by the VIRTUAL wave QW * wid + set, so
+// k_attn_warm / k_attn_rescore see no difference.
+template <int KS, int QW = 1>
+__global__ __launch_bounds__(FILT_NT / QW, (QW == 1 ? 2 : 1)) void k_attn_screen(AttnArgs p) {
+    constexpr int NWP = FILT_NW / QW;        // waves of the workgroup
+    constexpr int NTP = 64 * NWP;            // its threads
     constexpr int DP = KS * 16;
     constexpr int RSTR = DP * 2;             // LDS row stride in bytes: rows are dense (the LDS-DMA image is lane-linear)
     constexpr int CPR = DP / 8;              // 16-byte chunks per key row
@@ -918,7 +924,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     constexpr int SMASK = (KS % 8 == 4) ? 7 : 15;
     constexpr int TKS = screen_stage_keys(KS);   // keys per stage
     constexpr int NCH = TKS * CPR;
-    constexpr int NPF = NCH / FILT_NT;
+    constexpr int NPF = NCH / NTP;
     extern __shared__ __attribute__((aligned(16))) char fsm[];
     auto kbuf = [&](int b) -> char * { return fsm + b * (TKS * RSTR); };      // three stage buffers
     __shared__ int s_col;
@@ -943,13 +949,19 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     const int key_hi = p.key_hi < nk ? p.key_hi : nk;
     if (key_lo >= nk) return;                 // column exhausted by an earlier chunk (or by the warm-up kernel)
     const int32_t *kl = p.klist + (int64_t)c * p.Nk;
-    const int64_t slot = (int64_t)blk * QPBF + wid * 32 + r32;
-    const int qrow = p.qlist[slot];
-
-    // query operand: bf16(W[c][k] * x_q[k]) for k = 16 st + 8 h + j, and the margin from ||q||
-    bf16x8 breg[KS];
-    float qn2 = 0.f;
-    {
+    // query operands: bf16(W[c][k] * x_q[k]) for k = 16 st + 8 h + j, and the margin from ||q||, per query set
+    bf16x8 breg[QW][KS];
+    float thr_adj[QW];
+    int32_t *cand[QW];
+    int ncand[QW];
+    int vtid[QW];                             // thread number of the (virtual wave, lane) in the per-pair arrays
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs) {
+        const int vw = QW * wid + qs;
+        vtid[qs] = vw * 64 + lane;
+        const int64_t slot = (int64_t)blk * QPBF + vw * 32 + r32;
+        const int qrow = p.qlist[slot];
+        float qn2 = 0.f;
         const float *wq = p.Wp + (int64_t)c * DP + 8 * h;
         const float *xq = p.Xqp + (int64_t)(qrow < 0 ? 0 : qrow) * DP + 8 * h;
 #pragma unroll
@@ -963,30 +975,30 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 for (int j = 0; j < 4; ++j) {
                     const float q = wv[j] * xv[j];
                     qn2 += q * q;
-                    breg[st][4 * j4 + j] = (__bf16)q;
+                    breg[qs][st][4 * j4 + j] = (__bf16)q;
                 }
             }
         }
+        qn2 += __shfl_xor(qn2, 32);
+        const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
+        // threshold = the query's exact (k+1)-th largest logit so far (parked by its h == 0 lane)
+        const float thr = p.st_val[((int64_t)blockIdx.x * NLIST(p.k) + NLIST(p.k) - 1) * FILT_NT + (vtid[qs] & ~32)];
+        thr_adj[qs] = (qrow < 0) ? INFINITY : thr - qe;
+        cand[qs] = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + vtid[qs];
+        ncand[qs] = 0;
     }
-    qn2 += __shfl_xor(qn2, 32);
-    const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
-    // threshold = the query's exact (k+1)-th largest logit so far (parked by its h == 0 lane)
-    const float thr = p.st_val[((int64_t)blockIdx.x * NLIST(p.k) + NLIST(p.k) - 1) * FILT_NT + (tid & ~32)];
-    const float thr_adj = (qrow < 0) ? INFINITY : thr - qe;
-    int32_t *cand = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + tid;
-    int ncand = 0;
 
     // key staging, three LDS stage buffers: while stage t is computed the rows of stage t+1 are written to
     // their buffer, the rows of stage t+2 are in flight to registers and the key-list indices of stage
     // t+3 are in flight too, so neither the index -> row dependence nor the Infinity-Cache / HBM latency
     // is waited for.  Rows past the end of the chunk re-read its last key (no branch, no zero fill); the
     // candidate collection ignores them through `rem`.
-    static_assert(NCH % FILT_NT == 0, "key stage must divide evenly over the workgroup");
+    static_assert(NCH % NTP == 0, "key stage must divide evenly over the workgroup");
     // LDS unit n (16 bytes) of a stage buffer: wave `wid` fills pieces wid*NPF .. wid*NPF+NPF-1 of 1 KiB, lane l of
     // piece q is unit 64 q + l = (row, position); it receives chunk position ^ key(row) of that key row.
     // The pieces of wave `wid` cover exactly the rows [wid*RPW, wid*RPW + RPW) of the stage: one index load per
     // wave and stage (lane l fetches the index of row l % RPW), handed to the lanes of a piece by ds_bpermute.
-    constexpr int RPW = TKS / FILT_NW;        // key rows per wave and stage
+    constexpr int RPW = TKS / NWP;            // key rows per wave and stage
     static_assert(RPW * CPR == NPF * 64 && RPW <= 64, "a wave's pieces cover whole rows");
     int kix = 0;
     int urow4[NPF];                           // 4 * (row of the stage this lane fetches with piece i, relative to the wave)
@@ -1026,20 +1038,20 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     // wave, so it is kept short and branch-free: a 16-bit mask of the hits, stored with the tile's number
     // as ONE word per lane and tile.  k_attn_rescore unpacks the words (and drops the padding rows past the
     // end of the chunk, which hold copies of its last key).
-    auto collect = [&](const f32x16 &acc, int tile) {
+    auto collect = [&](const f32x16 &acc, int tile, int qs) {
 #ifdef FILT_NOCOLLECT      // timing experiments only (wrong results): what this path costs
-        ++ncand; return;
+        ++ncand[qs]; return;
 #endif
         // bit g = sign of (threshold - logit g): one subtract and one v_alignbit per logit, no compare / select
         // chain through vcc (logit 15 first, so that logit g ends at bit g)
         unsigned cm = 0;
 #pragma unroll
         for (int g = 15; g >= 0; --g)
-            cm = __builtin_amdgcn_alignbit(cm, __float_as_uint(thr_adj - acc[g]), 31);
+            cm = __builtin_amdgcn_alignbit(cm, __float_as_uint(thr_adj[qs] - acc[g]), 31);
         cm &= 0xffffu;
         if (cm) {
-            if (ncand < FILT_CAPH) cand[ncand * FILT_NT] = (int32_t)(((unsigned)tile << 16) | cm);
-            ++ncand;
+            if (ncand[qs] < FILT_CAPH) cand[qs][ncand[qs] * FILT_NT] = (int32_t)(((unsigned)tile << 16) | cm);
+            ++ncand[qs];
         }
     };
     // the 8 operations of a tile's row maximum, one at a time (slot fillers)
@@ -1086,10 +1098,14 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
         return *reinterpret_cast<const bf16x8 *>(buf + foff[st % NOFF] + tile * 32 * RSTR + ((2 * st) & ~SMASK) * 16);
     };
     bf16x8 fr[2][H];
-    f32x16 cacc[2];
-    float mx[2] = {0.f, 0.f};
+    f32x16 cacc[QW][2];
+    float mx[QW][2];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { cacc[0][g] = 0.f; cacc[1][g] = 0.f; }
+    for (int qs = 0; qs < QW; ++qs) {
+        mx[qs][0] = mx[qs][1] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { cacc[qs][0][g] = 0.f; cacc[qs][1][g] = 0.f; }
+    }
 #pragma unroll
     for (int i = 0; i < H; ++i) fr[0][i] = frag(kbuf(0), 0, i);
     __builtin_amdgcn_sched_barrier(0);
@@ -1117,9 +1133,13 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                 for (int i = 0; i < H; ++i) {
                     if (u == 0 && i == 0) {
 #pragma unroll
-                        for (int g = 0; g < 16; ++g) cacc[(s + PAR) & 1][g] = 0.f;
+                        for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) cacc[qs][(s + PAR) & 1][g] = 0.f;
                     }
-                    cacc[(s + PAR) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[u * H + i], cacc[(s + PAR) & 1], 0, 0, 0);
+#pragma unroll
+                    for (int qs = 0; qs < QW; ++qs)
+                        cacc[qs][(s + PAR) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
                     if (j + 1 < 2 * NT_STAGE)
                         fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
                     else
@@ -1137,7 +1157,10 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     if (u == 1) {                        // previous tile's row maximum, 8 ops over H slots
 #pragma unroll
                         for (int o = 0; o < 8; ++o)
-                            if (o * H / 8 == i) max_op(cacc[(s + 1 + PAR) & 1], mx[(s + 1 + PAR) & 1], o);
+                            if (o * H / 8 == i) {
+#pragma unroll
+                                for (int qs = 0; qs < QW; ++qs) max_op(cacc[qs][(s + 1 + PAR) & 1], mx[qs][(s + 1 + PAR) & 1], o);
+                            }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1156,7 +1179,7 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (j == 2 * NT_STAGE - 2) {
-                    const unsigned target = (unsigned)FILT_NW * (unsigned)(t + 1);
+                    const unsigned target = (unsigned)NWP * (unsigned)(t + 1);
 #ifdef FILT_TIMING
                     const unsigned long long tb0 = TSTAMP();
 #endif
@@ -1186,15 +1209,10 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
 #endif
             }
             if (s > 0 || t > 0) {                        // the tile before this one (s == 0: the previous stage's last)
-                if (__builtin_amdgcn_ballot_w64(mx[(s + 1 + PAR) & 1] > thr_adj) != 0) {
-#ifdef FILT_TIMING
-                    ++tm_coll;
-                    const unsigned long long tc0 = TSTAMP();
-                    collect(cacc[(s + 1 + PAR) & 1], t * NT_STAGE + s - 1);
-                    tm_ct += TSTAMP() - tc0;
-#else
-                    collect(cacc[(s + 1 + PAR) & 1], t * NT_STAGE + s - 1);
-#endif
+#pragma unroll
+                for (int qs = 0; qs < QW; ++qs) {
+                    if (__builtin_amdgcn_ballot_w64(mx[qs][(s + 1 + PAR) & 1] > thr_adj[qs]) != 0)
+                        collect(cacc[qs][(s + 1 + PAR) & 1], t * NT_STAGE + s - 1, qs);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1214,20 +1232,23 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_screen(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the stages past the end must not outlive the wave
     set_wave_prio(0);
-    auto last_tile = [&](const f32x16 &pa) {             // last tile of the chunk
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs) {                    // last tile of the chunk
+        const f32x16 &pa = ((nst * NT_STAGE - 1) & 1) ? cacc[qs][1] : cacc[qs][0];
         float m = 0.f;
 #pragma unroll
         for (int o = 0; o < 8; ++o) max_op(pa, m, o);
-        if (__builtin_amdgcn_ballot_w64(m > thr_adj) != 0) collect(pa, nst * NT_STAGE - 1);
-    };
-    if ((nst * NT_STAGE - 1) & 1) last_tile(cacc[1]); else last_tile(cacc[0]);
+        if (__builtin_amdgcn_ballot_w64(m > thr_adj[qs]) != 0) collect(pa, nst * NT_STAGE - 1, qs);
+    }
 #ifdef FILT_TIMING
     if (lane == 0) {
         atomicAdd(&g_filt_time[2], tm_bar); atomicAdd(&g_filt_time[3], (unsigned long long)nst);
         atomicAdd(&g_filt_time[4], TSTAMP() - ts_begin); atomicAdd(&g_filt_time[5], tm_coll); atomicAdd(&g_filt_time[6], tm_vm); atomicAdd(&g_filt_time[7], tm_ct);
     }
 #endif
-    p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + tid] = ncand;      // > FILT_CAPH: overflow, pair goes to the fp32 path
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs)
+        p.cand_cnt[(int64_t)blockIdx.x * FILT_NT + vtid[qs]] = ncand[qs];      // > FILT_CAPH: overflow, pair goes to the fp32 path
 }
 
 // ---- exact pass over the candidates of one chunk: every candidate is re-scored in fp32 (16 lanes per
@@ -1864,8 +1885,11 @@ template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
     const size_t lds = (size_t)3 * screen_stage_keys(KS) * (KS * 32);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
-    static std::atomic<size_t> granted{48 * 1024}, granted_w{48 * 1024};
-    int rc = set_lds_attr((const void *)k_attn_screen<KS>, lds, granted);
+    static std::atomic<size_t> granted{48 * 1024}, granted_w{48 * 1024}, granted2{48 * 1024};
+    // DDG_SCREEN_QW=2: 64 queries per wave (four-wave workgroups, every key fragment feeds two MFMAs)
+    static const int qw = [] { const char *e = getenv("DDG_SCREEN_QW"); return (e && e[0] == '2') ? 2 : 1; }();
+    int rc = qw == 2 ? set_lds_attr((const void *)k_attn_screen<KS, 2>, lds, granted2)
+                     : set_lds_attr((const void *)k_attn_screen<KS, 1>, lds, granted);
     if (rc) return rc;
     if ((rc = set_lds_attr((const void *)k_attn_warm<KS * 2, KCAP>, lds_w, granted_w))) return rc;
     // groups of workgroups (outer, bounds the parked state) x key chunks (inner).  Per chunk: the bf16
@@ -1881,7 +1905,8 @@ static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
         for (int64_t k0 = WARMK; k0 < a.Nk; k0 += len, len = fixed ? fixed : (2 * len < FILT_CHUNK_MAX ? 2 * len : FILT_CHUNK_MAX)) {
             b.key_lo = (int)k0;
             b.key_hi = (int)(k0 + len < a.Nk ? k0 + len : ((int64_t)1 << 31) - 1);
-            k_attn_screen<KS><<<(unsigned)gn, FILT_NT, lds, s>>>(b);
+            if (qw == 2) k_attn_screen<KS, 2><<<(unsigned)gn, FILT_NT / 2, lds, s>>>(b);
+            else k_attn_screen<KS, 1><<<(unsigned)gn, FILT_NT, lds, s>>>(b);
             k_attn_rescore<KS, KCAP><<<(unsigned)gn, FILT_NT, 0, s>>>(b);
         }
     }
