@@ -901,15 +901,22 @@ __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
     }
 }
 // keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
-__host__ __device__ constexpr int screen_stage_keys(int KS) {
-    return FILT_NW != 8 ? 64 : (KS <= 4 ? 256 : KS <= 8 ? 192 : KS <= 12 ? 128 : 96);     // 96 ... 147 KB for three buffers
+#ifndef SCREEN_HALF
+#define SCREEN_HALF 1               // 0: full-size stages also for QW = 2 (A/B builds)
+#endif
+__host__ __device__ constexpr int screen_stage_keys(int KS, int QW = 1) {
+    // QW = 2 and rows of <= 256 bytes: half-size stages, so that TWO four-wave workgroups (two waves per SIMD) fit a CU
+    return FILT_NW != 8 ? 64 : (KS <= 4 ? 256 : KS <= 8 ? 192 : KS <= 12 ? 128 : 96) / ((SCREEN_HALF && QW == 2 && KS <= 8) ? 2 : 1);     // 96 ... 147 KB for three buffers
 }
 // QW = query sets (32 queries each) per wave.  QW = 2: a workgroup is FILT_NW / 2 waves, every key fragment read from LDS
 // feeds two MFMAs (one per set): one ds_read_b128 per v_mfma_f32_32x32x16_bf16 is exactly the LDS peak of a CU, so with
 // QW = 1 the matrix pipe cannot pass ~85 %.  The per-pair arrays are indexed by the VIRTUAL wave QW * wid + set, so
 // k_attn_warm / k_attn_rescore see no difference.
+#ifndef SCREEN_LB1
+#define SCREEN_LB1 0                // 1: one wave per SIMD for every QW = 2 instantiation (A/B builds)
+#endif
 template <int KS, int QW = 1>
-__global__ __launch_bounds__(FILT_NT / QW, (QW == 1 ? 2 : 1)) void k_attn_screen(AttnArgs p) {
+__global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_LB1 && KS <= 8)) ? 2 : 1)) void k_attn_screen(AttnArgs p) {
     constexpr int NWP = FILT_NW / QW;        // waves of the workgroup
     constexpr int NTP = 64 * NWP;            // its threads
     constexpr int DP = KS * 16;
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(FILT_NT / QW, (QW == 1 ? 2 : 1)) void k_attn_screen
     // rows of equal parity get distinct XOR keys: (row >> 1) & 7.  Strides of 64 / 128 dwords (KS 8, 16)
     // need 16 distinct positions: key = row & 15.  Both keys are distinct inside every 16-lane group.
     constexpr int SMASK = (KS % 8 == 4) ? 7 : 15;
-    constexpr int TKS = screen_stage_keys(KS);   // keys per stage
+    constexpr int TKS = screen_stage_keys(KS, QW);   // keys per stage
     constexpr int NCH = TKS * CPR;
     constexpr int NPF = NCH / NTP;
     extern __shared__ __attribute__((aligned(16))) char fsm[];
@@ -1125,7 +1132,12 @@ __global__ __launch_bounds__(FILT_NT / QW, (QW == 1 ? 2 : 1)) void k_attn_screen
             // The SIMD's arbiter favours its oldest wave, and a dependent MFMA chain is always ready: left
             // alone, one wave of the pair runs ahead and then idles at the barrier while its partner runs
             // alone.  Priority falls with the tile index, so the wave that is behind owns the matrix pipe.
+            // (two workgroups per CU: their waves must not out-prioritise each other)
+#ifdef SCREEN_Q2_PRIO
             set_wave_prio(FILT_PRIO(s));
+#else
+            set_wave_prio((QW == 2 && KS <= 8) ? 0 : FILT_PRIO(s));
+#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int j = 2 * s + u;
@@ -1232,13 +1244,16 @@ __global__ __launch_bounds__(FILT_NT / QW, (QW == 1 ? 2 : 1)) void k_attn_screen
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of the stages past the end must not outlive the wave
     set_wave_prio(0);
-#pragma unroll
-    for (int qs = 0; qs < QW; ++qs) {                    // last tile of the chunk
-        const f32x16 &pa = ((nst * NT_STAGE - 1) & 1) ? cacc[qs][1] : cacc[qs][0];
+    auto last_tile = [&](const f32x16 &pa, int qs) {     // last tile of the chunk
         float m = 0.f;
 #pragma unroll
         for (int o = 0; o < 8; ++o) max_op(pa, m, o);
         if (__builtin_amdgcn_ballot_w64(m > thr_adj[qs]) != 0) collect(pa, nst * NT_STAGE - 1, qs);
+    };
+    // (a branch per parity, not a reference picked at run time: that would put the accumulators into scratch memory)
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs) {
+        if ((nst * NT_STAGE - 1) & 1) last_tile(cacc[qs][1], qs); else last_tile(cacc[qs][0], qs);
     }
 #ifdef FILT_TIMING
     if (lane == 0) {
@@ -1883,11 +1898,16 @@ static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_byte
 
 template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
-    const size_t lds = (size_t)3 * screen_stage_keys(KS) * (KS * 32);
+    // 64 queries per wave (four-wave workgroups, every key fragment feeds two MFMAs): the default for 256-byte key rows
+    // (D in (64, 128]: measured 5.6 % faster at the c4 shape -- half-size stages keep two waves per SIMD there); for wider
+    // rows only one workgroup fits a CU and it is slower.  DDG_SCREEN_QW=1 / 2 overrides.
+    static const int qw = [] {
+        const char *e = getenv("DDG_SCREEN_QW");
+        return (e && e[0] == '2') ? 2 : (e && e[0] == '1') ? 1 : (KS == 8 ? 2 : 1);
+    }();
+    const size_t lds = (size_t)3 * screen_stage_keys(KS, qw) * (KS * 32);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
     static std::atomic<size_t> granted{48 * 1024}, granted_w{48 * 1024}, granted2{48 * 1024};
-    // DDG_SCREEN_QW=2: 64 queries per wave (four-wave workgroups, every key fragment feeds two MFMAs)
-    static const int qw = [] { const char *e = getenv("DDG_SCREEN_QW"); return (e && e[0] == '2') ? 2 : 1; }();
     int rc = qw == 2 ? set_lds_attr((const void *)k_attn_screen<KS, 2>, lds, granted2)
                      : set_lds_attr((const void *)k_attn_screen<KS, 1>, lds, granted);
     if (rc) return rc;
