@@ -11,7 +11,8 @@
 // What autograd does in the reference is written out here layer by layer.  All GEMMs (forward
 // Y = A W^T, input gradients dA = dY W, weight gradients dW = dY^T A) run on the fp32 MFMA
 // (v_mfma_f32_32x32x2_f32): the step is 128 rows deep, so every GEMM is a handful of 32x32 tiles
-// and the step is launch-latency bound (about 50 short kernels); callers capture it in a HIP graph.
+// and the step is about 45 kernels of a few microseconds each: ddgani_amd replays it as a HIP graph in throughput mode
+// (model/Diffusion.py::GraphedSteps; the random-stream numbers then move in device memory, ddg_set_stream_offset).
 #include <math.h>
 #include "common.h"
 
