@@ -844,6 +844,25 @@ __global__ __launch_bounds__(256) void k_attn_wlist(AttnArgs p) {
 // fill at the last chunk).  Workgroup = 8 waves x 32 queries of one column sharing one key stream.
 // ---------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// Screening operands.  SCREEN_F16 = 1 (default): f16 with power-of-two scaling -- the same MFMA rate as bf16 and a unit
+// roundoff of 2^-11 instead of 2^-8, i.e. a rigorous margin 8x smaller and about a quarter fewer re-scored candidates.
+// Keys are stored as f16(kscale * x) (kscale: power of two, largest |element| in [0.5, 1)); a query's operand is
+// f16(qsc * q) with qsc the power of two that puts its largest |element| into [2^13, 2^14); thresholds are compared in
+// the scaled domain.  With a = qsc q, b = kscale k, |f16(a_d) - a_d| <= u |a_d| + 2^-25 (the second term covers
+// subnormal results), the same for b, |b_d| <= 1, exact f16 x f16 products and fp32 accumulation:
+//   |sum f16(a) f16(b) - sum a b| <= (2u + u^2 + DP 2^-23) ||a|| ||b|| + 2^-25 (1 + u) (sqrt(DP) ||a|| + DP) + DP 2^-50
+// SCREEN_F16 = 0 builds the bf16 screen of round 1 (FILT_EPS).
+#ifndef SCREEN_F16
+#define SCREEN_F16 1
+#endif
+#if SCREEN_F16
+typedef f16x8 scrx8;
+#define SCREEN_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define FILT_EPS16 1.01e-3f          // 2u + u^2 + DP 2^-23 for DP <= 256, rounded up
+#else
+typedef bf16x8 scrx8;
+#define SCREEN_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 #ifdef FILT_STATS   // experiments only: [0] re-scored, [2] batches, [3] tie-flagged pairs
 extern "C" int ddg_debug_filt_stats(unsigned long long *out4, int reset) {
     if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_filt_stats), 32) != hipSuccess) return DDG_E_LAUNCH;
@@ -957,7 +976,7 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
     if (key_lo >= nk) return;                 // column exhausted by an earlier chunk (or by the warm-up kernel)
     const int32_t *kl = p.klist + (int64_t)c * p.Nk;
     // query operands: bf16(W[c][k] * x_q[k]) for k = 16 st + 8 h + j, and the margin from ||q||, per query set
-    bf16x8 breg[QW][KS];
+    scrx8 breg[QW][KS];
     float thr_adj[QW];
     int32_t *cand[QW];
     int ncand[QW];
@@ -971,6 +990,24 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
         float qn2 = 0.f;
         const float *wq = p.Wp + (int64_t)c * DP + 8 * h;
         const float *xq = p.Xqp + (int64_t)(qrow < 0 ? 0 : qrow) * DP + 8 * h;
+#if SCREEN_F16
+        float qmax = 0.f;
+#pragma unroll
+        for (int st = 0; st < KS; ++st)
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wq + 16 * st + 4 * j4);
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xq + 16 * st + 4 * j4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qmax = fmaxf(qmax, fabsf(wv[j] * xv[j]));
+            }
+        qmax = fmaxf(qmax, __shfl_xor(qmax, 32));
+        int eq = 14;
+        if (qmax > 0.f && qmax < INFINITY && qrow >= 0) frexpf(qmax, &eq);
+        const float qsc = ldexpf(1.f, 14 - eq);
+#else
+        const float qsc = 1.f;
+#endif
 #pragma unroll
         for (int st = 0; st < KS; ++st) {
 #pragma unroll
@@ -982,15 +1019,28 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
                 for (int j = 0; j < 4; ++j) {
                     const float q = wv[j] * xv[j];
                     qn2 += q * q;
+#if SCREEN_F16
+                    breg[qs][st][4 * j4 + j] = (_Float16)(q * qsc);
+#else
                     breg[qs][st][4 * j4 + j] = (__bf16)q;
+#endif
                 }
             }
         }
         qn2 += __shfl_xor(qn2, 32);
-        const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
         // threshold = the query's exact (k+1)-th largest logit so far (parked by its h == 0 lane)
         const float thr = p.st_val[((int64_t)blockIdx.x * NLIST(p.k) + NLIST(p.k) - 1) * FILT_NT + (vtid[qs] & ~32)];
+#if SCREEN_F16
+        {   // margin and threshold in the scaled domain (see the bound above)
+            const float ksc = p.kscale[0];
+            const float an = qsc * sqrtf(qn2) * 1.000001f;                         // ||a||, rounded up
+            const float marg = FILT_EPS16 * an * (ksc * p.kmax[0]) + 0x1p-25f * 1.001f * (sqrtf((float)DP) * an + (float)DP) + 1e-30f;
+            thr_adj[qs] = (qrow < 0) ? INFINITY : thr * (qsc * ksc) - marg * 1.000001f;
+        }
+#else
+        const float qe = FILT_EPS * sqrtf(qn2) * 1.000001f * p.kmax[0] + 1e-30f;
         thr_adj[qs] = (qrow < 0) ? INFINITY : thr - qe;
+#endif
         cand[qs] = p.cand_pos + (int64_t)blockIdx.x * FILT_CAPH * FILT_NT + vtid[qs];
         ncand[qs] = 0;
     }
@@ -1102,9 +1152,9 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
         for (int m = 0; m < NOFF; ++m) foff[m] = r32 * RSTR + (((2 * m + h) ^ key) & SMASK) * 16;
     }
     auto frag = [&](const char *buf, int tile, int st) {
-        return *reinterpret_cast<const bf16x8 *>(buf + foff[st % NOFF] + tile * 32 * RSTR + ((2 * st) & ~SMASK) * 16);
+        return *reinterpret_cast<const scrx8 *>(buf + foff[st % NOFF] + tile * 32 * RSTR + ((2 * st) & ~SMASK) * 16);
     };
-    bf16x8 fr[2][H];
+    scrx8 fr[2][H];
     f32x16 cacc[QW][2];
     float mx[QW][2];
 #pragma unroll
@@ -1151,7 +1201,7 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
                     }
 #pragma unroll
                     for (int qs = 0; qs < QW; ++qs)
-                        cacc[qs][(s + PAR) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][i], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
+                        cacc[qs][(s + PAR) & 1] = SCREEN_MFMA(fr[j & 1][i], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
                     if (j + 1 < 2 * NT_STAGE)
                         fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
                     else
@@ -1537,18 +1587,32 @@ __global__ __launch_bounds__(FILT_NT, 2) void k_attn_warm(AttnArgs p) {
     }
 }
 
-// keys -> bf16, and the largest key 2-norm (rounded up) for the screening margin; one wave per row
-__global__ void k_keys_bf16(const float *__restrict__ Xkp, int64_t rows, int DP, __bf16 *__restrict__ Xkh,
-                            unsigned *__restrict__ kmax_bits) {
+// keys -> screening operand (f16 of kscale * x, or bf16 of x), and the largest key 2-norm (of x, rounded up) for the
+// screening margin; one wave per row.  max_bits: largest |element| (k_maxabs), kscale_out: the power of two derived from it
+__global__ void k_keys_screen(const float *__restrict__ Xkp, int64_t rows, int DP, __bf16 *__restrict__ Xkh,
+                              unsigned *__restrict__ kmax_bits, const unsigned *__restrict__ max_bits,
+                              float *__restrict__ kscale_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+#if SCREEN_F16
+    const float mxv = __uint_as_float(max_bits[0]);
+    int e2 = 0;
+    if (mxv > 0.f && mxv < INFINITY) frexpf(mxv, &e2);
+    const float ksc = ldexpf(1.f, -e2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) kscale_out[0] = ksc;
+    _Float16 *out = reinterpret_cast<_Float16 *>(Xkh);
+#endif
     float best = 0.f;
     for (int64_t r = row0; r < rows; r += nw) {
         float s2 = 0.f;
         for (int e = lane; e < DP; e += 64) {
             const float v = Xkp[r * DP + e];
+#if SCREEN_F16
+            out[r * DP + e] = (_Float16)(v * ksc);
+#else
             Xkh[r * DP + e] = (__bf16)v;
+#endif
             s2 += v * v;
         }
         s2 = wave_sum(s2);
@@ -1916,13 +1980,21 @@ static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
     // screening pass, then the exact fp32 pass over its candidates.
     AttnArgs b = a;
     const int64_t fixed = filt_chunk_fixed();
+    // growth of the chunk length in percent (200: every chunk as long as everything before it)
+    static const int64_t growth = [] { const char *e = getenv("DDG_FILT_GROWTH"); const int64_t g = e ? atoll(e) : 200; return g < 110 ? 110 : g; }();
     for (int64_t g0 = 0; g0 < nblocks_max; g0 += FILT_GROUP) {
         const int64_t gn = nblocks_max - g0 < FILT_GROUP ? nblocks_max - g0 : FILT_GROUP;
         b.blk_lo = (int)g0;
         b.key_lo = 0; b.key_hi = WARMK;
         k_attn_warm<KS * 2, KCAP><<<(unsigned)gn, FILT_NT, lds_w, s>>>(b);          // positions [0, WARMK), exact fp32
         int64_t len = fixed ? fixed : WARMK;
-        for (int64_t k0 = WARMK; k0 < a.Nk; k0 += len, len = fixed ? fixed : (2 * len < FILT_CHUNK_MAX ? 2 * len : FILT_CHUNK_MAX)) {
+        auto next_len = [&](int64_t l) {
+            if (fixed) return fixed;
+            int64_t n = (l * growth / 100 / 128) * 128;
+            if (n <= l) n = l + 128;
+            return n < FILT_CHUNK_MAX ? n : (int64_t)FILT_CHUNK_MAX;
+        };
+        for (int64_t k0 = WARMK; k0 < a.Nk; k0 += len, len = next_len(len)) {
             b.key_lo = (int)k0;
             b.key_hi = (int)(k0 + len < a.Nk ? k0 + len : ((int64_t)1 << 31) - 1);
             if (qw == 2) k_attn_screen<KS, 2><<<(unsigned)gn, FILT_NT / 2, lds, s>>>(b);
@@ -2078,7 +2150,12 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
     if (!same) k_pad_rows<<<egrid(Nq * DP), 256, 0, s>>>(Xq0, w.Xqp, Nq, D, DP);
     k_pad_rows<<<egrid((int64_t)C * DP), 256, 0, s>>>(W, w.Wp, C, D, DP);
     if (qpb == QPBF)
-        k_keys_bf16<<<egrid(Nk * 64), 256, 0, s>>>(w.Xkp, Nk, DP, w.Xkh, reinterpret_cast<unsigned *>(w.flags + 1));
+    {
+        k_maxabs<<<egrid(Nk * DP), 256, 0, s>>>(w.Xkp, Nk * DP, reinterpret_cast<unsigned *>(w.flags + 2));
+        k_keys_screen<<<egrid(Nk * 64), 256, 0, s>>>(w.Xkp, Nk, DP, w.Xkh, reinterpret_cast<unsigned *>(w.flags + 1),
+                                                     reinterpret_cast<const unsigned *>(w.flags + 2),
+                                                     reinterpret_cast<float *>(w.flags + 3));
+    }
     if ((k > Nk ? Nk : k) > DDG_MAX_TOPK_REG && window_path(Nk) && !window_f32()) {
         k_maxabs<<<egrid(Nk * DP), 256, 0, s>>>(w.Xkp, Nk * DP, reinterpret_cast<unsigned *>(w.flags + 2));
         k_keys_split<<<egrid(Nk * DP), 256, 0, s>>>(w.Xkp, Nk, DP, reinterpret_cast<_Float16 *>(w.Xkh),
