@@ -24,7 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA", dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA", dense (the screen runs on f16 since round 2: same peak)
 
 
 def parse():
@@ -304,7 +304,7 @@ def main():
             "metric": "imputed rows/sec (T-step reverse diffusion + top_k attn fill)",
             "value": N / (dt / a.steps), "unit": "rows/s", "n_gpus": world, "n_ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32 (bf16 MFMA screening, exact fp32 re-scoring of every candidate)" if filt else
+            "dtype": ("f32 (f16 MFMA screening with a rigorous margin, exact fp32 re-scoring of every candidate)" if filt else
                       "f32 (logits on the f16 MFMA from operands split in two halves, error 3 * 2^-22 sum|q||k|; fp32 accumulation)"
                       if large_k and not radix and not win_f32 else "f32"),
             "data": "synthetic",
@@ -314,7 +314,7 @@ def main():
             "phases_ms": {"prepare(+allgather)": sum(prep_ms) / len(prep_ms), "select": sel,
                           "fill": sum(fill_ms) / len(fill_ms), "sampler+merge": sum(samp_ms) / len(samp_ms)},
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_attn_screen (bf16 MFMA similarity screening; its time here includes the exact fp32 "
+                         "kernel": ("k_attn_screen (f16 MFMA similarity screening, power-of-two scaled operands; its time here includes the exact fp32 "
                                     "k_attn_rescore and k_attn_warm launches of the select phase, about 12 % of it)" if filt else
                                     "k_attn<MODE_HIST> (fp32 MFMA similarity, 5-level radix select of the k-th logit)" if radix else
                                     "k_attn<MODE_WIN> + k_attn<MODE_WFILL> (window selection: two full similarity passes, "
