@@ -934,8 +934,11 @@ __host__ __device__ constexpr int screen_stage_keys(int KS, int QW = 1) {
 #ifndef SCREEN_LB1
 #define SCREEN_LB1 0                // 1: one wave per SIMD for every QW = 2 instantiation (A/B builds)
 #endif
-template <int KS, int QW = 1>
+// KSC = 16-deep steps that hold data (ceil(D / 16) <= KS): the zero padding up to the row stride is copied to LDS with
+// the row but neither read from there nor multiplied (c3: D = 176 in 192-element rows, 11 of 12 steps).
+template <int KS, int QW = 1, int KSC = KS>
 __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_LB1 && KS <= 8)) ? 2 : 1)) void k_attn_screen(AttnArgs p) {
+    static_assert(KSC >= 1 && KSC <= KS, "compute steps");
     constexpr int NWP = FILT_NW / QW;        // waves of the workgroup
     constexpr int NTP = 64 * NWP;            // its threads
     constexpr int DP = KS * 16;
@@ -1164,7 +1167,8 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
         for (int g = 0; g < 16; ++g) { cacc[qs][0][g] = 0.f; cacc[qs][1][g] = 0.f; }
     }
 #pragma unroll
-    for (int i = 0; i < H; ++i) fr[0][i] = frag(kbuf(0), 0, i);
+    for (int i = 0; i < H; ++i)
+        if (i < KSC) fr[0][i] = frag(kbuf(0), 0, i);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef FILT_TIMING
     unsigned long long tm_bar = 0, tm_coll = 0, tm_vm = 0, tm_ct = 0, ts_begin = TSTAMP();
@@ -1201,10 +1205,11 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
                     }
 #pragma unroll
                     for (int qs = 0; qs < QW; ++qs)
-                        cacc[qs][(s + PAR) & 1] = SCREEN_MFMA(fr[j & 1][i], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
-                    if (j + 1 < 2 * NT_STAGE)
-                        fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
-                    else
+                        if (u * H + i < KSC)
+                            cacc[qs][(s + PAR) & 1] = SCREEN_MFMA(fr[j & 1][i], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
+                    if (j + 1 < 2 * NT_STAGE) {
+                        if (((j + 1) & 1) * H + i < KSC) fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
+                    } else if (i < KSC)
                         fr[0][i] = frag(base_n, 0, i);
                     if (j == 0 && i == 0) load_idx(t + 2);        // key-list indices of stage t+2
                     if (j == 2 * NT_STAGE - 2) {
@@ -1960,6 +1965,36 @@ static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_byte
     return DDG_OK;
 }
 
+// one instantiation of the screening kernel: opt into its LDS size once, then launch
+template <int KS, int QW, int KSC>
+static int screen_one(const AttnArgs &b, int64_t gn, bool prepare, hipStream_t s) {
+    const size_t lds = (size_t)3 * screen_stage_keys(KS, QW) * (KS * 32);
+    static std::atomic<size_t> granted{48 * 1024};
+    if (prepare) return set_lds_attr((const void *)k_attn_screen<KS, QW, KSC>, lds, granted);
+    k_attn_screen<KS, QW, KSC><<<(unsigned)gn, FILT_NT / QW, lds, s>>>(b);
+    return DDG_OK;
+}
+// pad = 16-deep steps of the row stride that hold only zero padding (0 .. 3; rows are padded to 64 elements)
+template <int KS>
+static int screen_launch(int qw, int pad, const AttnArgs &b, int64_t gn, bool prepare, hipStream_t s) {
+    if (qw == 2) {
+        if constexpr (KS == 8) {
+            switch (pad) {
+            case 1: return screen_one<KS, 2, KS - 1>(b, gn, prepare, s);
+            case 2: return screen_one<KS, 2, KS - 2>(b, gn, prepare, s);
+            case 3: return screen_one<KS, 2, KS - 3>(b, gn, prepare, s);
+            }
+        }
+        return screen_one<KS, 2, KS>(b, gn, prepare, s);
+    }
+    switch (pad) {
+    case 1: return screen_one<KS, 1, KS - 1>(b, gn, prepare, s);
+    case 2: return screen_one<KS, 1, KS - 2>(b, gn, prepare, s);
+    case 3: return screen_one<KS, 1, KS - 3>(b, gn, prepare, s);
+    }
+    return screen_one<KS, 1, KS>(b, gn, prepare, s);
+}
+
 template <int KS, int KCAP>
 static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
     // 64 queries per wave (four-wave workgroups, every key fragment feeds two MFMAs): the default for 256-byte key rows
@@ -1969,11 +2004,12 @@ static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
         const char *e = getenv("DDG_SCREEN_QW");
         return (e && e[0] == '2') ? 2 : (e && e[0] == '1') ? 1 : (KS == 8 ? 2 : 1);
     }();
-    const size_t lds = (size_t)3 * screen_stage_keys(KS, qw) * (KS * 32);
     const size_t lds_w = (size_t)2 * TK * (KS * 16 + 4) * 4;
-    static std::atomic<size_t> granted{48 * 1024}, granted_w{48 * 1024}, granted2{48 * 1024};
-    int rc = qw == 2 ? set_lds_attr((const void *)k_attn_screen<KS, 2>, lds, granted2)
-                     : set_lds_attr((const void *)k_attn_screen<KS, 1>, lds, granted);
+    static std::atomic<size_t> granted_w{48 * 1024};
+    static const bool nopad = [] { const char *e = getenv("DDG_SCREEN_PAD"); return e && e[0] == '1'; }();   // A/B: multiply the padding too
+    int pad = nopad ? 0 : KS - (a.D + 15) / 16;
+    if (pad < 0 || pad > 3) pad = 0;
+    int rc = screen_launch<KS>(qw, pad, a, 0, true, s);
     if (rc) return rc;
     if ((rc = set_lds_attr((const void *)k_attn_warm<KS * 2, KCAP>, lds_w, granted_w))) return rc;
     // groups of workgroups (outer, bounds the parked state) x key chunks (inner).  Per chunk: the bf16
@@ -1997,8 +2033,7 @@ static int launch_filt(const AttnArgs &a, int64_t nblocks_max, hipStream_t s) {
         for (int64_t k0 = WARMK; k0 < a.Nk; k0 += len, len = next_len(len)) {
             b.key_lo = (int)k0;
             b.key_hi = (int)(k0 + len < a.Nk ? k0 + len : ((int64_t)1 << 31) - 1);
-            if (qw == 2) k_attn_screen<KS, 2><<<(unsigned)gn, FILT_NT / 2, lds, s>>>(b);
-            else k_attn_screen<KS, 1><<<(unsigned)gn, FILT_NT, lds, s>>>(b);
+            screen_launch<KS>(qw, pad, b, gn, false, s);
             k_attn_rescore<KS, KCAP><<<(unsigned)gn, FILT_NT, 0, s>>>(b);
         }
     }
