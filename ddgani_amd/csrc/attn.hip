@@ -225,12 +225,23 @@ __device__ __forceinline__ void topk_finish(const AttnArgs &p, float (&lst)[KCAP
 // time each), fp32 accumulation.  |error| <= 3 * 2^-22 sum_d |q_d||k_d| + fp32 accumulation, the class of the fp32
 // chain's own rounding; the key tiles keep their byte size (4 bytes per element), so the staging is shared.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int KS4, int MODE, int KCAP, bool SPLIT = false>
+// VALU instructions scheduled behind each MFMA of the pipelined loop (per-logit work of a tile / MFMAs of a tile)
+#ifndef PIPE_VALU_WIN
+#define PIPE_VALU_WIN 5
+#define PIPE_VALU_ONE 7
+#define PIPE_VALU_BLK 10
+#endif
+#define PIPE_VALU(MODE, ONE) ((MODE) == MODE_WIN ? PIPE_VALU_WIN : (ONE) ? PIPE_VALU_ONE : PIPE_VALU_BLK)
+// PIPE (SPLIT only; 0 = off): the key stream is software-pipelined one tile deep, the MFMAs of tile t+1 interleaved with the
+// per-logit work of tile t in one basic block; PIPE - 1 = trailing 16-deep steps of the row stride that hold only zero
+// padding (not multiplied).  Same products in the same order as PIPE = 0: bit-identical logits.
+template <int KS4, int MODE, int KCAP, bool SPLIT = false, int PIPE = 0>
 __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     static_assert(!SPLIT || MODE == MODE_WIN || MODE == MODE_WFILL, "split arithmetic: window passes only");
+    static_assert(PIPE == 0 || (SPLIT && PIPE - 1 < KS4 / 2), "pipelined loop: split window passes only");
     constexpr int DP = KS4 * 8;
     constexpr int KS = KS4 / 2;            // 16-deep steps (SPLIT)
-    constexpr int XOFF = (SPLIT && MODE == MODE_WFILL) ? 512 : 0;      // floats of the two fp32 side tiles (MODE_WFILL)
+    constexpr int XOFF = (SPLIT && MODE == MODE_WFILL) ? 768 : 0;      // floats of the three fp32 side tiles (MODE_WFILL)
     constexpr int LSTR = DP + 4;
     constexpr int NPF = KS4 / 4;           // float4 prefetch registers per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     // ---- query operand in registers: breg[4u+s] = W[c][k] * x_q[k], k = 8u + 4h + s
     f16x8 bh[SPLIT ? KS : 1], bl[SPLIT ? KS : 1];
     float qinv = 1.f;                      // SPLIT: logit = accumulator * qinv
+    const int ksc = (p.D + 15) >> 4;       // SPLIT: 16-deep steps that hold data
     if constexpr (SPLIT) {
         // q_d = W[c][d] x_q[d] for d = 16 u + 8 h + j, scaled by a power of two so that max |q_d| lies in [2^13, 2^14)
         const float *wq = p.Wp + (int64_t)c * DP + 8 * h;
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     f32x4 pf[NPF];
     bool pfx_ok = false;
     float pfx = 0.f;                       // SPLIT + MODE_WFILL: fp32 value st_c of the key row's column block (side tile)
-    float *xs0 = extra + QPB, *xs1 = extra + QPB + 256;
+    float *xs0 = extra + QPB, *xs1 = extra + QPB + 256;       // (a third one follows: pipelined loop)
     const float *ksrc = SPLIT ? reinterpret_cast<const float *>(p.Xks) : p.Xkp;     // rows of DP * 4 bytes either way
     auto prefetch = [&](int t) {
 #ifdef EXP_NOLOAD      // timing experiments only (wrong results): every tile re-reads the first rows
@@ -407,22 +419,15 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         if (SPLIT && MODE == MODE_WFILL) pfx = p.Xkp[(int64_t)(kidx < 0 ? 0 : kidx) * DP + off_c + (st_c < d_c ? st_c : 0)];
 #endif
     };
-    auto commit = [&](float *buf) {
+    auto commit = [&](float *buf, float *xsd) {
         float *dst = buf + st_row * LSTR + st_c * 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) *reinterpret_cast<f32x4 *>(dst + 32 * i) = pfx_ok ? pf[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (SPLIT && MODE == MODE_WFILL) (buf == kbuf0 ? xs0 : xs1)[tid] = (pfx_ok && st_c < d_c) ? pfx : 0.f;
+        if (SPLIT && MODE == MODE_WFILL) xsd[tid] = (pfx_ok && st_c < d_c) ? pfx : 0.f;
     };
 
-    const int ntk = (nk + TK - 1) / TK;
-    if (ntk > 0) { prefetch(0); commit(kbuf0); }
-    __syncthreads();
-
-    for (int t = 0; t < ntk; ++t) {
-        float *cur = (t & 1) ? kbuf1 : kbuf0;
-        float *nxt = (t & 1) ? kbuf0 : kbuf1;
-        if (t + 1 < ntk) prefetch(t + 1);
-
+    // the similarity of one 32-key tile against the wave's 32 queries
+    auto mma = [&](const float *cur) {
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[g] = 0.f;
@@ -435,6 +440,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             const float qinvx = qinv * 0x1p-11f;
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
+                if (u >= KS - 3 && u >= ksc) continue;     // steps that hold only the zero padding of the row (uniform)
                 const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab + 8 * u);            // halves 16 u + 8 h ..
                 const f16x8 al = *reinterpret_cast<const f16x8 *>(Ab + DP / 2 + 8 * u);   // their remainders
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc, 0, 0, 0);
@@ -452,7 +458,10 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], breg[4 * u + s], acc, 0, 0, 0);
             }
         }
-
+        return acc;
+    };
+    // per-logit work of a mode on the tile's 32 x 32 logits (xst: fp32 side tile of the key rows' column block)
+    auto epi = [&](f32x16 &acc, int t, const float *cur, const float *xst) {
         const int rem = nk - t * TK;          // valid key rows in this tile (>= 1)
         const bool full = rem >= TK;
 
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             }
             // The common path is straight-line code per column class (the class is workgroup-uniform): weights of all 16
             // logits, accumulation, and ONE wave-wide test per tile whether any logit fell into the selected bin.
-            const float *xsb = SPLIT ? (cur == kbuf0 ? xs0 : xs1) : cur + off_c;    // fp32 values of the key rows' column block
+            const float *xsb = SPLIT ? xst : cur + off_c;    // fp32 values of the key rows' column block
             constexpr int XSTR = SPLIT ? 8 : LSTR;
             unsigned inbm = 0;
             auto weight = [&](int g) {
@@ -595,9 +604,157 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                 }
             }
         }
+    };
 
-        if (t + 1 < ntk) commit(nxt);
-        __syncthreads();
+    const int ntk = (nk + TK - 1) / TK;
+    if (ntk > 0) { prefetch(0); commit(kbuf0, xs0); }
+    __syncthreads();
+
+    if constexpr (PIPE > 0) {
+        // Software pipeline one tile deep.  The key rows of tile t+2 are written over tile t's buffer, which only the MFMAs
+        // of the previous iteration read; the side tiles rotate over three.  The accumulator pair of tile t+1 (leading and
+        // cross products) is combined into logits at the end of the iteration.  The last tile (the only one that can be
+        // partial) takes the plain path.  Host: not for column blocks wider than 8 (their accumulate step reads the key tile)
+        // and not for the WIN_MINMAX pass.
+        constexpr int KSC = KS - (PIPE - 1);
+        constexpr int NM = 3 * KSC;                 // MFMAs per tile
+        if (ntk > 0) {
+            if (ntk > 1) prefetch(1);
+            f32x16 pa, px;
+            {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { pa[g] = 0.f; px[g] = 0.f; }
+                const float *Ab = kbuf0 + r32 * LSTR + 4 * h;
+#pragma unroll
+                for (int u = 0; u < KSC; ++u) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab + 8 * u);
+                    const f16x8 al = *reinterpret_cast<const f16x8 *>(Ab + DP / 2 + 8 * u);
+                    pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], pa, 0, 0, 0);
+                    px = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], px, 0, 0, 0);
+                    px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], px, 0, 0, 0);
+                }
+            }
+            const float qinvx = qinv * 0x1p-11f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) pa[g] = fmaf(px[g], qinvx, pa[g] * qinv);      // the logits of tile 0
+            if (ntk > 1) commit(kbuf1, xs1);
+            __syncthreads();
+            int x_cur = 0, x_new = 512;             // side tile of tile t, of tile t+2 (floats past xs0)
+            auto piped = [&](auto onec) {
+                constexpr bool ONE = decltype(onec)::value;      // MODE_WFILL: column blocks of one element
+                for (int t = 0; t + 1 < ntk; ++t) {
+                    float *cur = (t & 1) ? kbuf1 : kbuf0;
+                    float *nxt = (t & 1) ? kbuf0 : kbuf1;
+                    if (t + 2 < ntk) prefetch(t + 2);
+                    f32x16 na, nx;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) { na[g] = 0.f; nx[g] = 0.f; }
+                    const float *Ab = nxt + r32 * LSTR + 4 * h;
+                    const float *xsb = xs0 + x_cur;
+                    unsigned inbm = 0;
+                    // ---- one basic block, written out slot by slot: each MFMA of tile t+1 is followed by the fragment reads
+                    // of the next step or by the whole work of one logit of tile t (its side-tile values are read one logit
+                    // ahead); sched_barrier keeps the slots as written
+                    f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab), al = *reinterpret_cast<const f16x8 *>(Ab + DP / 2);
+                    f16x8 ahn = ah, aln = al;
+                    [[maybe_unused]] f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;          // side-tile values of the logit in work
+                    [[maybe_unused]] uint32_t *hist = reinterpret_cast<uint32_t *>(extra) + (wid * 32 + r32) * WHSTRIDE;
+                    auto side = [&](int g) {
+                        const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                        if constexpr (MODE == MODE_WFILL) {
+                            if constexpr (ONE) {
+                                xa[0] = xsb[kr * 8];
+                            } else {
+                                xa = *reinterpret_cast<const f32x4 *>(xsb + kr * 8);
+                                xb = *reinterpret_cast<const f32x4 *>(xsb + kr * 8 + 4);
+                            }
+                        }
+                    };
+                    side(0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const int u = m / 3, r = m % 3;
+                        if (r == 0) na = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], na, 0, 0, 0);
+                        else if (r == 1) nx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], nx, 0, 0, 0);
+                        else nx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], nx, 0, 0, 0);
+                        if (r == 0 && u + 1 < KSC) {
+                            ahn = *reinterpret_cast<const f16x8 *>(Ab + 8 * (u + 1));
+                            aln = *reinterpret_cast<const f16x8 *>(Ab + DP / 2 + 8 * (u + 1));
+                        }
+                        if (r == 2) { ah = ahn; al = aln; }
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) {
+                            if ((g * NM) / 16 != m) continue;
+                            float v = pa[g];
+                            asm volatile("" : "+v"(v));       // the logit's work starts in this slot, not earlier
+                            if constexpr (MODE == MODE_WIN) {
+                                smax = fmaxf(smax, v);
+                                int idx = (int)floorf(fmaf(v, winv, nwl));
+                                idx = min(max(idx, -1), WBINS) + 1;
+                                atomicAdd(&hist[idx], 1u);
+                            } else {
+                                const f32x4 ya = xa, yb = xb;
+                                if (g + 1 < 16) side(g + 1);
+                                const float tt = fmaf(v, winv, nwl);
+                                const bool keep = tt >= fb1;
+                                const float w = keep ? __builtin_amdgcn_exp2f(fmaf(v, 1.44269504088896340736f, nsmax2)) : 0.f;
+                                Z += w;
+                                inbm |= (tt >= fb && !keep) ? (1u << g) : 0u;
+                                if constexpr (ONE) {
+                                    accr[0] += w * ya[0];
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { accr[e] += w * ya[e]; accr[4 + e] += w * yb[e]; }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // (the accumulations stay in this block: without the pins they are sunk past the commit below)
+                    asm volatile("" : "+v"(Z), "+v"(smax), "+v"(inbm));
+                    if constexpr (MODE == MODE_WFILL) {
+#pragma unroll
+                        for (int e = 0; e < (ONE ? 1 : 8); ++e) asm volatile("" : "+v"(accr[e]));
+                    }
+                    if constexpr (MODE == MODE_WFILL) {
+                        if (__any(inbm != 0)) {              // rare: keys inside the selected bin are listed for k_attn_wlist
+                            int *lcur = reinterpret_cast<int *>(extra);
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) {
+                                if (inbm & (1u << g)) {
+                                    const int kr = (g & 3) + 8 * (g >> 2) + 4 * h;
+                                    const int i = atomicAdd(&lcur[wid * 32 + r32], 1);
+                                    if (i < p.wcap) {
+                                        const int64_t o = (((int64_t)blockIdx.x * QPB) + wid * 32 + r32) * p.wcap + i;
+                                        p.lpos[o] = t * TK + kr;
+                                        p.lval[o] = pa[g];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (t + 2 < ntk) commit(cur, xs0 + x_new);
+                    __syncthreads();
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) pa[g] = fmaf(nx[g], qinvx, na[g] * qinv);      // the logits of tile t+1
+                    x_cur = x_cur == 512 ? 0 : x_cur + 256;
+                    x_new = x_new == 512 ? 0 : x_new + 256;
+                }
+            };
+            if (MODE == MODE_WFILL && d_c == 1) piped(std::true_type{}); else piped(std::false_type{});
+            epi(pa, ntk - 1, ((ntk - 1) & 1) ? kbuf1 : kbuf0, xs0 + x_cur);
+        }
+    } else {
+        for (int t = 0; t < ntk; ++t) {
+            float *cur = (t & 1) ? kbuf1 : kbuf0;
+            float *nxt = (t & 1) ? kbuf0 : kbuf1;
+            if (t + 1 < ntk) prefetch(t + 1);
+            f32x16 acc = mma(cur);
+            epi(acc, t, cur, (t & 1) ? xs1 : xs0);
+            if (t + 1 < ntk) commit(nxt, (t & 1) ? xs0 : xs1);
+            __syncthreads();
+        }
     }
 
     // ---- per-mode finish
@@ -920,12 +1077,18 @@ __device__ __forceinline__ uint32_t mul_small(uint32_t x) {
     }
 }
 // keys per LDS stage of the screening kernel: three stage buffers must fit in 160 KB
+#ifndef SCREEN_LA2
+#define SCREEN_LA2 4                // fragments in flight per wave for QW = 2 with rows wider than 256 bytes
+#endif
+#ifndef SCREEN_HALF_KS
+#define SCREEN_HALF_KS 8            // QW = 2: half-size stages and two workgroups per CU up to this many steps per row
+#endif
 #ifndef SCREEN_HALF
 #define SCREEN_HALF 1               // 0: full-size stages also for QW = 2 (A/B builds)
 #endif
 __host__ __device__ constexpr int screen_stage_keys(int KS, int QW = 1) {
     // QW = 2 and rows of <= 256 bytes: half-size stages, so that TWO four-wave workgroups (two waves per SIMD) fit a CU
-    return FILT_NW != 8 ? 64 : (KS <= 4 ? 256 : KS <= 8 ? 192 : KS <= 12 ? 128 : 96) / ((SCREEN_HALF && QW == 2 && KS <= 8) ? 2 : 1);     // 96 ... 147 KB for three buffers
+    return FILT_NW != 8 ? 64 : (KS <= 4 ? 256 : KS <= 8 ? 192 : KS <= 12 ? 128 : 96) / ((SCREEN_HALF && QW == 2 && KS <= SCREEN_HALF_KS) ? 2 : 1);     // 96 ... 147 KB for three buffers
 }
 // QW = query sets (32 queries each) per wave.  QW = 2: a workgroup is FILT_NW / 2 waves, every key fragment read from LDS
 // feeds two MFMAs (one per set): one ds_read_b128 per v_mfma_f32_32x32x16_bf16 is exactly the LDS peak of a CU, so with
@@ -937,7 +1100,7 @@ __host__ __device__ constexpr int screen_stage_keys(int KS, int QW = 1) {
 // KSC = 16-deep steps that hold data (ceil(D / 16) <= KS): the zero padding up to the row stride is copied to LDS with
 // the row but neither read from there nor multiplied (c3: D = 176 in 192-element rows, 11 of 12 steps).
 template <int KS, int QW = 1, int KSC = KS>
-__global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_LB1 && KS <= 8)) ? 2 : 1)) void k_attn_screen(AttnArgs p) {
+__global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_LB1 && KS <= SCREEN_HALF_KS)) ? 2 : 1)) void k_attn_screen(AttnArgs p) {
     static_assert(KSC >= 1 && KSC <= KS, "compute steps");
     constexpr int NWP = FILT_NW / QW;        // waves of the workgroup
     constexpr int NTP = 64 * NWP;            // its threads
@@ -1157,7 +1320,11 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
     auto frag = [&](const char *buf, int tile, int st) {
         return *reinterpret_cast<const scrx8 *>(buf + foff[st % NOFF] + tile * 32 * RSTR + ((2 * st) & ~SMASK) * 16);
     };
-    scrx8 fr[2][H];
+    // ring of the LA fragments in flight: slot n of a stage (n = 12-slot tile number * KS + step) consumes entry n % LA
+    // and refills it with the fragment of slot n + LA
+    constexpr int LA = (QW == 2 && KS > 8) ? SCREEN_LA2 : H;
+    static_assert(LA <= H && (NT_STAGE * KS) % LA == 0, "fragment ring");
+    scrx8 fr[LA];
     f32x16 cacc[QW][2];
     float mx[QW][2];
 #pragma unroll
@@ -1167,8 +1334,8 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
         for (int g = 0; g < 16; ++g) { cacc[qs][0][g] = 0.f; cacc[qs][1][g] = 0.f; }
     }
 #pragma unroll
-    for (int i = 0; i < H; ++i)
-        if (i < KSC) fr[0][i] = frag(kbuf(0), 0, i);
+    for (int i = 0; i < LA; ++i)
+        if (i < KSC) fr[i] = frag(kbuf(0), 0, i);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef FILT_TIMING
     unsigned long long tm_bar = 0, tm_coll = 0, tm_vm = 0, tm_ct = 0, ts_begin = TSTAMP();
@@ -1206,11 +1373,15 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
 #pragma unroll
                     for (int qs = 0; qs < QW; ++qs)
                         if (u * H + i < KSC)
-                            cacc[qs][(s + PAR) & 1] = SCREEN_MFMA(fr[j & 1][i], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
-                    if (j + 1 < 2 * NT_STAGE) {
-                        if (((j + 1) & 1) * H + i < KSC) fr[(j + 1) & 1][i] = frag(base, (j + 1) >> 1, ((j + 1) & 1) * H + i);
-                    } else if (i < KSC)
-                        fr[0][i] = frag(base_n, 0, i);
+                            cacc[qs][(s + PAR) & 1] = SCREEN_MFMA(fr[(j * H + i) % LA], breg[qs][u * H + i], cacc[qs][(s + PAR) & 1], 0, 0, 0);
+                    {
+                        constexpr int SLOTS = NT_STAGE * KS;
+                        const int m = j * H + i + LA;             // the slot this entry serves next
+                        if (m < SLOTS) {
+                            if (m % KS < KSC) fr[(j * H + i) % LA] = frag(base, m / KS, m % KS);
+                        } else if (m - SLOTS < KSC)
+                            fr[(j * H + i) % LA] = frag(base_n, 0, m - SLOTS);
+                    }
                     if (j == 0 && i == 0) load_idx(t + 2);        // key-list indices of stage t+2
                     if (j == 2 * NT_STAGE - 2) {
 #pragma unroll
@@ -1954,15 +2125,30 @@ static int set_lds_attr(const void *fn, size_t lds, std::atomic<size_t> &granted
     return DDG_OK;
 }
 
-template <int KS4, int MODE, int KCAP, bool SPLIT = false>
+template <int KS4, int MODE, int KCAP, bool SPLIT = false, int PIPE = 0>
 static int launch_attn(const AttnArgs &a, int64_t nblocks_max, size_t extra_bytes, hipStream_t s) {
     const size_t lds = (size_t)2 * TK * (KS4 * 8 + 4) * 4 + extra_bytes;
     static std::atomic<size_t> granted{48 * 1024};
-    int rc = set_lds_attr((const void *)k_attn<KS4, MODE, KCAP, SPLIT>, lds, granted);
+    int rc = set_lds_attr((const void *)k_attn<KS4, MODE, KCAP, SPLIT, PIPE>, lds, granted);
     if (rc) return rc;
-    k_attn<KS4, MODE, KCAP, SPLIT><<<(unsigned)nblocks_max, 256, lds, s>>>(a);
+    k_attn<KS4, MODE, KCAP, SPLIT, PIPE><<<(unsigned)nblocks_max, 256, lds, s>>>(a);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
+}
+// split window pass, pipelined (pipe = 1 + padding steps to skip, at most 1) or plain (pipe = 0)
+template <int KS4, int MODE>
+static int launch_split(int pipe, const AttnArgs &a, int64_t nblocks_max, size_t extra_bytes, hipStream_t s) {
+    if (pipe == 1) return launch_attn<KS4, MODE, 1, true, 1>(a, nblocks_max, extra_bytes, s);
+    if constexpr (KS4 >= 4) {
+        if (pipe == 2) return launch_attn<KS4, MODE, 1, true, 2>(a, nblocks_max, extra_bytes, s);
+    }
+    return launch_attn<KS4, MODE, 1, true, 0>(a, nblocks_max, extra_bytes, s);
+}
+// DDG_WIN_PIPE=0: plain loops (A/B; the logits are bit-identical either way)
+static int window_pipe(int KS4, int D) {
+    static const bool off = [] { const char *e = getenv("DDG_WIN_PIPE"); return e && e[0] == '0'; }();
+    if (off) return 0;
+    return (KS4 >= 4 && KS4 / 2 - (D + 15) / 16 >= 1) ? 2 : 1;
 }
 
 // one instantiation of the screening kernel: opt into its LDS size once, then launch
@@ -2057,7 +2243,8 @@ static int run_select(AttnArgs &a, int64_t nb, int mode, hipStream_t s) {
         auto pass = [&](int level, int sample) {
             a.level = level;
             a.sample = sample;
-            return f32 ? launch_attn<KS4, MODE_WIN, 1, false>(a, nb, ex, s) : launch_attn<KS4, MODE_WIN, 1, true>(a, nb, ex, s);
+            if (f32) return launch_attn<KS4, MODE_WIN, 1, false>(a, nb, ex, s);
+            return launch_split<KS4, MODE_WIN>(level == WIN_MINMAX ? 0 : window_pipe(KS4, a.D), a, nb, ex, s);
         };
         if ((rc = pass(WIN_MINMAX, 1))) return rc;
         if ((rc = pass(WIN_SHIST, 1))) return rc;
@@ -2081,7 +2268,8 @@ static int run_fill(AttnArgs &a, int64_t nb, int dcmax, bool window, hipStream_t
             const int64_t gn = nb - g0 < WIN_GROUP ? nb - g0 : WIN_GROUP;
             b.blk_lo = (int)g0;
             int rc = window_f32() ? launch_attn<KS4, MODE_WFILL, 1, false>(b, gn, (size_t)(QPB + 256 * a.dcs) * 4, s)
-                                  : launch_attn<KS4, MODE_WFILL, 1, true>(b, gn, (size_t)(QPB + 512 + 256 * a.dcs) * 4, s);
+                                  : launch_split<KS4, MODE_WFILL>(dcmax <= 8 ? window_pipe(KS4, a.D) : 0, b, gn,
+                                                                  (size_t)(QPB + 768 + 256 * a.dcs) * 4, s);
             if (rc) return rc;
             k_attn_wlist<<<(unsigned)gn, 256, 0, s>>>(b);
         }
