@@ -607,8 +607,10 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     };
 
     const int ntk = (nk + TK - 1) / TK;
-    if (ntk > 0) { prefetch(0); commit(kbuf0, xs0); }
-    __syncthreads();
+    if constexpr (PIPE == 0) {
+        if (ntk > 0) { prefetch(0); commit(kbuf0, xs0); }
+        __syncthreads();
+    }
 
     if constexpr (PIPE > 0) {
         // Software pipeline one tile deep.  The key rows of tile t+2 are written over tile t's buffer, which only the MFMAs
@@ -618,17 +620,85 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         // and not for the WIN_MINMAX pass.
         constexpr int KSC = KS - (PIPE - 1);
         constexpr int NM = 3 * KSC;                 // MFMAs per tile
+        // Key rows go straight from global memory into LDS (LDS-DMA: no staging registers, no ds_write).  A DMA piece is 64
+        // lanes x 16 bytes, lane-linear in LDS, so rows are dense (DP * 4 bytes: a multiple of 64 banks) and bank conflicts
+        // of the fragment reads are removed by an XOR swizzle of the 16-byte chunk position with key = row & 15, applied
+        // to the SOURCE address of the DMA and to the ds_read address.  Wave w fills the 1 KiB pieces w*NPC .. of a tile =
+        // its rows 8 w .. 8 w + 7: one key-list load per wave and tile (lane l: row l & 7), issued a whole tile before the
+        // rows that depend on it, handed to the lanes by ds_bpermute -- the same index serves the side tile's gather.
+        // Rows past the end of the list re-read its last key (the last tile's per-logit work masks them).
+        constexpr int RB = DP * 4;                  // bytes per key row
+        constexpr int CPR = DP / 4;                 // 16-byte chunks per row
+        constexpr int NPC = RB / 128;               // pieces per wave and tile
+        static_assert(NPC * 1024 == 8 * RB && CPR % 16 == 0, "a wave's pieces cover its eight rows");
+        int kix = 0;
+        uint32_t usrc[NPC];
+        int urow4[NPC];
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int n = i * 64 + lane;
+            const int rrow = n / CPR, pos = n - rrow * CPR;
+            const int key = (wid * 8 + rrow) & 15;
+            urow4[i] = rrow * 4;
+            usrc[i] = (uint32_t)(((pos & ~15) | ((pos ^ key) & 15)) * 16);
+        }
+        auto load_kix = [&](int t) {
+            int pos = t * TK + wid * 8 + (lane & 7);
+            pos = pos < nk ? pos : nk - 1;
+            kix = kl[(int64_t)pos * kstride];
+        };
+        auto dma_tile = [&](float *buf) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const uint32_t kid = (uint32_t)__builtin_amdgcn_ds_bpermute(urow4[i], kix);
+                const char *src = reinterpret_cast<const char *>(ksrc) + (uint64_t)kid * RB + usrc[i];
+                __builtin_amdgcn_global_load_lds(
+                    reinterpret_cast<const __attribute__((address_space(1))) void *>(reinterpret_cast<uintptr_t>(src)),
+                    reinterpret_cast<__attribute__((address_space(3))) void *>(
+                        (uint32_t)(uintptr_t)(reinterpret_cast<char *>(buf) + (wid * NPC + i) * 1024)), 16, 0, 0);
+            }
+        };
+        // side tile (MODE_WFILL): thread (st_row, st_c) gathers fp32 value st_c of key row st_row's column block
+        auto side_prefetch = [&](int t) {
+            if constexpr (MODE == MODE_WFILL) {
+                const uint32_t kid = (uint32_t)__builtin_amdgcn_ds_bpermute((lane >> 3) * 4, kix);
+                pfx_ok = t * TK + st_row < nk;
+                pfx = p.Xkp[(int64_t)kid * DP + off_c + (st_c < d_c ? st_c : 0)];
+            }
+        };
+        auto side_commit = [&](float *xsd) {
+            if constexpr (MODE == MODE_WFILL) xsd[tid] = (pfx_ok && st_c < d_c) ? pfx : 0.f;
+        };
+        // fragment u' (chunk 2 u' + h) of tile row r32: position (2 u' + h) ^ key; eight lane offsets cover the low bits
+        int foff[8];
+        {
+            const int hk = h ^ (r32 & 15);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) foff[m] = r32 * RB + ((2 * m) ^ hk) * 16;
+        }
+        auto frag = [&](const float *buf, int up) {
+            return *reinterpret_cast<const f16x8 *>(reinterpret_cast<const char *>(buf) + foff[up & 7] + 32 * (up & ~7));
+        };
         if (ntk > 0) {
-            if (ntk > 1) prefetch(1);
+            load_kix(0);
+            dma_tile(kbuf0);
+            side_prefetch(0);
+            load_kix(1);
+            dma_tile(kbuf1);
+            side_commit(xs0);
+            side_prefetch(1);
+            load_kix(2);
+            side_commit(xs1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             f32x16 pa, px;
             {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { pa[g] = 0.f; px[g] = 0.f; }
-                const float *Ab = kbuf0 + r32 * LSTR + 4 * h;
 #pragma unroll
                 for (int u = 0; u < KSC; ++u) {
-                    const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab + 8 * u);
-                    const f16x8 al = *reinterpret_cast<const f16x8 *>(Ab + DP / 2 + 8 * u);
+                    const f16x8 ah = frag(kbuf0, u);
+                    const f16x8 al = frag(kbuf0, DP / 16 + u);
                     pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], pa, 0, 0, 0);
                     px = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], px, 0, 0, 0);
                     px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], px, 0, 0, 0);
@@ -637,25 +707,26 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             const float qinvx = qinv * 0x1p-11f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) pa[g] = fmaf(px[g], qinvx, pa[g] * qinv);      // the logits of tile 0
-            if (ntk > 1) commit(kbuf1, xs1);
-            __syncthreads();
+            __syncthreads();                        // every wave has read tile 0: its buffer takes tile 2
             int x_cur = 0, x_new = 512;             // side tile of tile t, of tile t+2 (floats past xs0)
             auto piped = [&](auto onec) {
                 constexpr bool ONE = decltype(onec)::value;      // MODE_WFILL: column blocks of one element
                 for (int t = 0; t + 1 < ntk; ++t) {
                     float *cur = (t & 1) ? kbuf1 : kbuf0;
                     float *nxt = (t & 1) ? kbuf0 : kbuf1;
-                    if (t + 2 < ntk) prefetch(t + 2);
+                    // tile t+2 (rows and side values; past the end: copies of the last key), key-list indices of tile t+3
+                    dma_tile(cur);
+                    side_prefetch(t + 2);
+                    load_kix(t + 3);
                     f32x16 na, nx;
 #pragma unroll
                     for (int g = 0; g < 16; ++g) { na[g] = 0.f; nx[g] = 0.f; }
-                    const float *Ab = nxt + r32 * LSTR + 4 * h;
                     const float *xsb = xs0 + x_cur;
                     unsigned inbm = 0;
                     // ---- one basic block, written out slot by slot: each MFMA of tile t+1 is followed by the fragment reads
                     // of the next step or by the whole work of one logit of tile t (its side-tile values are read one logit
                     // ahead); sched_barrier keeps the slots as written
-                    f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab), al = *reinterpret_cast<const f16x8 *>(Ab + DP / 2);
+                    f16x8 ah = frag(nxt, 0), al = frag(nxt, DP / 16);
                     f16x8 ahn = ah, aln = al;
                     [[maybe_unused]] f32x4 xa = {0.f, 0.f, 0.f, 0.f}, xb = xa;          // side-tile values of the logit in work
                     [[maybe_unused]] uint32_t *hist = reinterpret_cast<uint32_t *>(extra) + (wid * 32 + r32) * WHSTRIDE;
@@ -679,8 +750,8 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                         else if (r == 1) nx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], nx, 0, 0, 0);
                         else nx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], nx, 0, 0, 0);
                         if (r == 0 && u + 1 < KSC) {
-                            ahn = *reinterpret_cast<const f16x8 *>(Ab + 8 * (u + 1));
-                            aln = *reinterpret_cast<const f16x8 *>(Ab + DP / 2 + 8 * (u + 1));
+                            ahn = frag(nxt, u + 1);
+                            aln = frag(nxt, DP / 16 + u + 1);
                         }
                         if (r == 2) { ah = ahn; al = aln; }
 #pragma unroll
@@ -712,7 +783,8 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // (the accumulations stay in this block: without the pins they are sunk past the commit below)
-                    asm volatile("" : "+v"(Z), "+v"(smax), "+v"(inbm));
+                    if constexpr (MODE == MODE_WIN) asm volatile("" : "+v"(smax));
+                    else asm volatile("" : "+v"(Z), "+v"(inbm));
                     if constexpr (MODE == MODE_WFILL) {
 #pragma unroll
                         for (int e = 0; e < (ONE ? 1 : 8); ++e) asm volatile("" : "+v"(accr[e]));
@@ -734,7 +806,8 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                             }
                         }
                     }
-                    if (t + 2 < ntk) commit(cur, xs0 + x_new);
+                    side_commit(xs0 + x_new);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+2 are in LDS
                     __syncthreads();
 #pragma unroll
                     for (int g = 0; g < 16; ++g) pa[g] = fmaf(nx[g], qinvx, na[g] * qinv);      // the logits of tile t+1
@@ -742,7 +815,13 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                     x_new = x_new == 512 ? 0 : x_new + 256;
                 }
             };
-            if (MODE == MODE_WFILL && d_c == 1) piped(std::true_type{}); else piped(std::false_type{});
+            if (MODE == MODE_WFILL && d_c == 1) {
+                piped(std::true_type{});
+#pragma unroll
+                for (int e = 1; e < 8; ++e) accr[e] = 0.f;      // (dead inside the loop: seven registers less)
+            } else {
+                piped(std::false_type{});
+            }
             epi(pa, ntk - 1, ((ntk - 1) & 1) ? kbuf1 : kbuf0, xs0 + x_cur);
         }
     } else {
