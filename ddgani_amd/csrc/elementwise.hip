@@ -250,7 +250,24 @@ __global__ void k_head_reverse(const float *__restrict__ y, const float *__restr
                                uint64_t stream_id, const int32_t *__restrict__ offsets,
                                const uint8_t *__restrict__ is_cat, int C, float *__restrict__ out, int64_t rows, int D,
                                int rows_pb) {
+    // Work split without divergence: only the categorical fields go through a (row, field) phase -- their softmax needs
+    // the whole block; the sigmoid of a numeric element is applied where the element is consumed, in the elementwise
+    // reverse-step phase (one thread per (row, field) over ALL fields made every wave run the 8-element softmax path and
+    // the sigmoid path one after the other: 0.35 of the HBM rate).  Same expressions per element: bit-identical results.
     extern __shared__ float tile[];
+    uint8_t *kind = reinterpret_cast<uint8_t *>(tile + (size_t)rows_pb * D);      // [D] 1: element of a categorical field
+    int *catf = reinterpret_cast<int *>(kind + ((D + 3) & ~3));                     // [C] the categorical fields
+    __shared__ int s_ncat;
+    if (threadIdx.x == 0) s_ncat = 0;
+    __syncthreads();
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        const uint8_t ic = is_cat[f];
+        if (ic) catf[atomicAdd(&s_ncat, 1)] = f;
+        for (int j = offsets[f]; j < offsets[f + 1]; ++j) kind[j] = ic;
+    }
+    __syncthreads();
+    const int ncat = s_ncat;
+    auto pred_of = [&](float v, int col) { return kind[col] ? v : 1.f / (1.f + expf(-v)); };
     const int64_t nblk = ceil_div64(rows, rows_pb);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t r0 = blk * rows_pb;
@@ -266,46 +283,50 @@ __global__ void k_head_reverse(const float *__restrict__ y, const float *__restr
             for (int i = threadIdx.x; i < nel; i += blockDim.x) tile[i] = y[base + i];
         }
         __syncthreads();
-        for (int w = threadIdx.x; w < nr * C; w += blockDim.x) {
-            const int r = w / C, f = w - r * C;
+        for (int w = threadIdx.x; w < nr * ncat; w += blockDim.x) {
+            const int r = w / ncat, f = catf[w - r * ncat];
             const int a = offsets[f], b = offsets[f + 1];
             float *p = tile + r * D;
-            if (is_cat[f]) {
-                float mx = p[a];
-                for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
-                float s = 0.f;
-                for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
-                for (int j = a; j < b; ++j) p[j] = p[j] / s;
-            } else {
-                for (int j = a; j < b; ++j) p[j] = 1.f / (1.f + expf(-p[j]));
-            }
+            float mx = p[a];
+            for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
+            float s = 0.f;
+            for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
+            for (int j = a; j < b; ++j) p[j] = p[j] / s;
         }
         __syncthreads();
         if ((base & 3) == 0) {
             const int ng = (nel + 3) / 4;
+            const int cstep = (int)((4 * blockDim.x) % (unsigned)D);
+            int col = (4 * threadIdx.x) % D;             // column of element i0 (the tile starts at a row start)
             for (int g = threadIdx.x; g < ng; g += blockDim.x) {
                 const int i0 = g * 4;
                 const int64_t e0 = base + i0;
+                int cc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cc[c] = col + c < D ? col + c : col + c - D;
                 if (i0 + 3 < nel) {
                     const f32x4 a = *reinterpret_cast<const f32x4 *>(xt + e0);
                     const f32x4 b = *reinterpret_cast<const f32x4 *>(x + e0);
                     const f32x4 m = *reinterpret_cast<const f32x4 *>(M + e0);
                     const f32x4 zz = z ? *reinterpret_cast<const f32x4 *>(z + e0) : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
+                    const f32x4 pv = *reinterpret_cast<const f32x4 *>(tile + i0);
                     f32x4 r;
-                    r.x = rev_one(a.x, b.x, m.x, tile[i0], zz.x, k); r.y = rev_one(a.y, b.y, m.y, tile[i0 + 1], zz.y, k);
-                    r.z = rev_one(a.z, b.z, m.z, tile[i0 + 2], zz.z, k); r.w = rev_one(a.w, b.w, m.w, tile[i0 + 3], zz.w, k);
+                    r.x = rev_one(a.x, b.x, m.x, pred_of(pv.x, cc[0]), zz.x, k); r.y = rev_one(a.y, b.y, m.y, pred_of(pv.y, cc[1]), zz.y, k);
+                    r.z = rev_one(a.z, b.z, m.z, pred_of(pv.z, cc[2]), zz.z, k); r.w = rev_one(a.w, b.w, m.w, pred_of(pv.w, cc[3]), zz.w, k);
                     *reinterpret_cast<f32x4 *>(out + e0) = r;
                 } else {
                     const f32x4 z4 = z ? f32x4{0, 0, 0, 0} : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
                     for (int c = 0; c < 4 && i0 + c < nel; ++c)
-                        out[e0 + c] = rev_one(xt[e0 + c], x[e0 + c], M[e0 + c], tile[i0 + c], z ? z[e0 + c] : z4[c], k);
+                        out[e0 + c] = rev_one(xt[e0 + c], x[e0 + c], M[e0 + c], pred_of(tile[i0 + c], cc[c]), z ? z[e0 + c] : z4[c], k);
                 }
+                col += cstep;
+                if (col >= D) col -= D;
             }
         } else {
             for (int i = threadIdx.x; i < nel; i += blockDim.x) {
                 const int64_t e = base + i;
                 const float zz = z ? z[e] : philox_normal4(seed, stream_id, (uint64_t)(e >> 2))[e & 3];
-                out[e] = rev_one(xt[e], x[e], M[e], tile[i], zz, k);
+                out[e] = rev_one(xt[e], x[e], M[e], pred_of(tile[i], i % D), zz, k);
             }
         }
         __syncthreads();
@@ -337,7 +358,7 @@ extern "C" int ddg_head_reverse_step(const float *y, const float *x_t, const flo
     int rows_pb = 8192 / D;
     if (rows_pb < 1) return DDG_E_UNSUPPORTED;
     if (rows_pb > 64) rows_pb = 64;
-    const size_t lds = (size_t)rows_pb * D * sizeof(float);
+    const size_t lds = (size_t)rows_pb * D * sizeof(float) + ((D + 3) & ~3) + (size_t)C * sizeof(int);
     const int64_t nblk = ceil_div64(rows, rows_pb);
     const int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     k_head_reverse<<<grid, 256, lds, (hipStream_t)stream>>>(y, x_t, x, M, z, k, seed, stream_id, offsets, is_cat, C, out,

@@ -13,6 +13,7 @@
 // is one 16-byte LDS read; A and B use the same permutation, so the dot products are unchanged
 // up to fp32 summation order.
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <stdlib.h>
 
@@ -405,6 +406,177 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
     LIN_STATS()
 }
 
+// ---------------------------------------------------------------------------------------------
+// The split layer with WIDE column tiles (the sampler's full-table calls, 16-byte operand loads).  k_linear_split is
+// bound by the VALU work of staging: the A operand's prologue (BatchNorm + ReLU + a Philox dropout mask per float4) and
+// the split of both operands are redone for every 128-column tile of a row tile, and a 176-wide output wastes 31 % of
+// its two tiles.  Here eight waves own 32 rows x 96 columns each: WR x WC = 4 x 2 (128 x 192, outputs up to 192 wide) or
+// 2 x 4 (64 x 384), so that a 176- or 352-wide layer is ONE column tile and the prologue runs once per element.  Two LDS
+// buffers and one barrier per 32-deep chunk: the split + commit of chunk c+1 and the loads of chunk c+2 are in the same
+// stretch of code as the MFMAs of chunk c, and the two waves of a SIMD overlap one's VALU with the other's MFMAs.
+// Same products in the same order per output element as k_linear_split: bit-identical results.
+// ---------------------------------------------------------------------------------------------
+template <int PRO, int WR, int WC>
+__global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
+    static_assert(WR * WC == 8, "eight waves");
+    constexpr int KCH = 32;
+    constexpr int SSTR = 4 * KCH + 16;          // bytes per LDS row: KCH hi halves | KCH lo halves | pad
+    constexpr int BMW = 32 * WR, BNW = 96 * WC;
+    constexpr int NPA = BMW / 64, NPB = BNW / 64;      // float4 per thread and chunk (64 rows per pass of the workgroup)
+    static_assert(NPA * 64 == BMW && NPB * 64 == BNW, "tile rows are a multiple of the staging pass");
+    constexpr int BUFB = (BMW + BNW) * SSTR;    // bytes per buffer: A tile | B tile
+    extern __shared__ __attribute__((aligned(16))) char wlds[];
+    static_assert(2 * BUFB >= 8 * 3 * 2 * 32 * 8, "the buffers hold the statistics partials");
+    double(*red)[3][2][32] = reinterpret_cast<double(*)[3][2][32]>(wlds);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.y * BNW;
+    const int nchunks = (p.in + KCH - 1) / KCH;
+    const int64_t ntiles = ceil_div64(p.rows, BMW);
+    const float keep_scale = 1.f / (1.f - p.drop_p);
+
+    double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+    const int st_c4 = tid & 7, st_r = tid >> 3;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * BMW;
+        f32x16 accH[3], accX[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { accH[b][g] = 0.f; accX[b][g] = 0.f; }
+
+        int trows[NPA];
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int64_t row = row0 + st_r + 64 * i;
+            trows[i] = 0;
+            if ((PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) && row < p.rows)
+                trows[i] = min(max(p.t ? (int)p.t[row] : p.t_uniform, 0), p.emb_rows - 1);
+        }
+
+        f32x4 pa[NPA], pb[NPB];
+        auto fetch = [&](int chunk) {
+            const int k0 = chunk * KCH + st_c4 * 4;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) pa[i] = lin_stage_a<PRO>(p, row0 + st_r + 64 * i, k0, trows[i], keep_scale, true);
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) pb[i] = lin_stage_b(p, col0 + st_r + 64 * i, k0, true);
+        };
+        auto commit = [&](char *buf) {
+            char *As = buf, *Bs = buf + BMW * SSTR;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const int rl = st_r + 64 * i;
+                split4(pa[i], hi, lo);
+                *reinterpret_cast<f16x4 *>(&As[rl * SSTR + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&As[rl * SSTR + 2 * KCH + st_c4 * 8]) = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                const int rl = st_r + 64 * i;
+                split4(pb[i], hi, lo);
+                *reinterpret_cast<f16x4 *>(&Bs[rl * SSTR + st_c4 * 8]) = hi;
+                *reinterpret_cast<f16x4 *>(&Bs[rl * SSTR + 2 * KCH + st_c4 * 8]) = lo;
+            }
+        };
+
+        fetch(0);
+        commit(wlds);
+        if (nchunks > 1) fetch(1);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const char *cur = wlds + (c & 1) * BUFB;
+            const char *Ab = cur + (wr * 32 + r32) * SSTR + 16 * h;
+            const char *Bb = cur + BMW * SSTR + (wc * 96 + r32) * SSTR + 16 * h;
+#pragma unroll
+            for (int u = 0; u < KCH / 16; ++u) {
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(Ab + 32 * u);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(Ab + 2 * KCH + 32 * u);
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) {
+                    const f16x8 bh = *reinterpret_cast<const f16x8 *>(Bb + cb * 32 * SSTR + 32 * u);
+                    const f16x8 bl = *reinterpret_cast<const f16x8 *>(Bb + cb * 32 * SSTR + 2 * KCH + 32 * u);
+                    accH[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accH[cb], 0, 0, 0);
+                    accX[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accX[cb], 0, 0, 0);
+                    accX[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accX[cb], 0, 0, 0);
+                }
+            }
+            // chunk c+1 into the other buffer (last read by the MFMAs of chunk c-1, a barrier ago), chunk c+2 into registers
+            if (c + 1 < nchunks) commit(wlds + ((c + 1) & 1) * BUFB);
+            if (c + 2 < nchunks) fetch(c + 2);
+            __syncthreads();
+        }
+        // epilogue: + bias, store, fp64 column statistics
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            const int col = col0 + wc * 96 + ct * 32 + r32;
+            const bool cok = col < p.out;
+            const float bj = cok ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int64_t row = row0 + wr * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (cok && row < p.rows) {
+                    const float v = accH[ct][g] + accX[ct][g] * (1.f / SPLIT_LO_SCALE) + bj;
+                    p.Y[row * p.out + col] = v;
+                    s1[ct] += (double)v;
+                    s2[ct] += (double)v * (double)v;
+                }
+            }
+        }
+    }
+    if (p.stats) {                                 // (every wave is past the last tile's barrier: the buffers are free)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            double a = s1[ct], b = s2[ct];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            if (h == 0) { red[wid][ct][0][r32] = a; red[wid][ct][1][r32] = b; }
+        }
+        __syncthreads();
+        if (wr == 0 && h == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int col = col0 + wc * 96 + ct * 32 + r32;
+                if (col < p.out) {
+                    double a = 0, b = 0;
+#pragma unroll
+                    for (int q = 0; q < WR; ++q) { a += red[q * WC + wc][ct][0][r32]; b += red[q * WC + wc][ct][1][r32]; }
+                    atomicAdd(&p.stats[col], a);
+                    atomicAdd(&p.stats[p.out + col], b);
+                }
+            }
+        }
+    }
+}
+
+template <int PRO, int WR, int WC>
+static int launch_wide(const LinArgs &p, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (32 * WR + 96 * WC) * (4 * 32 + 16);
+    static std::atomic<int> granted{0};
+    if (!granted.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_linear_wide<PRO, WR, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            fprintf(stderr, "ddgani: hipFuncSetAttribute(%zu): %s\n", lds, hipGetErrorString(e));
+            return DDG_E_LAUNCH;
+        }
+        granted.store(1, std::memory_order_release);
+    }
+    const int64_t ntiles = ceil_div64(p.rows, 32 * WR);
+    const int ncol = (p.out + 96 * WC - 1) / (96 * WC);
+    int64_t g = ntiles;
+    const int64_t cap = (256 + ncol - 1) / ncol;            // one resident workgroup per CU
+    if (g > cap) g = cap;
+    if (g >= 8) g -= g % 8;
+    k_linear_wide<PRO, WR, WC><<<dim3((unsigned)g, (unsigned)ncol), 512, lds, s>>>(p);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
 // rows from which the split kernel serves a layer (the sampler's full-table calls); below it -- every B = 128 training
 // step, the small fixtures -- the fp32 kernel, whose arithmetic the training-trajectory pins were taken with.
 // DDG_LINEAR_F32=1 in the environment (read once) keeps the fp32 kernel everywhere (A/B timing).
@@ -535,6 +707,19 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
         if (g >= 8) g -= g % 8;
         dim3 grid2((unsigned)g, (unsigned)ncol);
         const bool fast = (p.A2 == nullptr) && ((p.in & 3) == 0);
+        // wide column tiles (DDG_LINEAR_WIDE=0: the 128-column kernel, A/B)
+        static const bool wide = [] { const char *e = getenv("DDG_LINEAR_WIDE"); return !(e && e[0] == '0'); }();
+        if (fast && wide) {
+#define LAUNCH_WIDE(PRO_) return p.out <= 192 ? launch_wide<PRO_, 4, 2>(p, s) : launch_wide<PRO_, 2, 4>(p, s);
+            switch (prologue) {
+                case DDG_PRO_NONE: LAUNCH_WIDE(DDG_PRO_NONE)
+                case DDG_PRO_ADD_EMB: LAUNCH_WIDE(DDG_PRO_ADD_EMB)
+                case DDG_PRO_BN_RELU: LAUNCH_WIDE(DDG_PRO_BN_RELU)
+                case DDG_PRO_EMB_RELU: LAUNCH_WIDE(DDG_PRO_EMB_RELU)
+                default: return DDG_E_ARG;
+            }
+#undef LAUNCH_WIDE
+        }
 #define LAUNCH_SPLIT(PRO_)                                                          \
         if (!fast) k_linear_split<PRO_, 1, 32, false><<<grid2, 256, 0, s>>>(p);     \
         else if (rt == 1 && kch == 64) k_linear_split<PRO_, 1, 64, true><<<grid2, 256, 0, s>>>(p);   \

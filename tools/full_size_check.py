@@ -83,7 +83,7 @@ def main():
            "phases_ms": ph, "select_flops": flops, "select_PFLOPs": flops / (ph["select"] * 1e-3) / 1e15,
            "frac_of_bf16_peak": flops / (ph["select"] * 1e-3) / 2.5e15,
            "parity_shard": {"query_rows": R, "keys": N, "missing_cells": int(miss.sum().item()),
-                            "max_abs_diff_vs_fp32_path": float(cell_err.max().item()),
+                            "max_abs_diff_vs_fp32_path": float(cell_err.max().item()) if cell_err.numel() else 0.0,
                             "cells_beyond_1e-5": bad,
                             "observed_cells_untouched": bool(torch.equal(got[~miss], Xq[~miss]))}}
     print(json.dumps(res))
