@@ -122,7 +122,7 @@ def other_rooflines(ops, P, xd, Md, lay, T, sched_host, reps=5):
     split = rows >= 8192
     byts = 5.0 * 4.0 * rows * D                           # y, x_t, x, M in; x_{t-1} out (noise on chip)
     return {
-        "gemm": {"kernel": "k_linear_split (4 dense layers of one denoiser call; f16 MFMA on operands split in two halves, "
+        "gemm": {"kernel": "k_linear_wide (4 dense layers of one denoiser call; f16 MFMA on operands split in two halves, "
                            "fp32-class)" if split else "k_linear (fp32 MFMA)",
                  "bound": "mfma", "achieved": flops / t_gemm / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                  "frac": flops / t_gemm / 1e12 / PEAK_F32_MFMA_TFLOPS, "launch_ms": t_gemm * 1e3,

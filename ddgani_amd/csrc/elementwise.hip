@@ -204,8 +204,23 @@ template <bool MERGE>
 __global__ void k_head_merge(const float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ M,
                              const int32_t *__restrict__ offsets, const uint8_t *__restrict__ is_cat, int C,
                              float *__restrict__ out, int64_t rows, int D, int rows_pb) {
+    // as in k_head_reverse: the (row, field) phase only for the categorical fields; a numeric element's sigmoid is
+    // applied where the element is written back
     extern __shared__ float tile[];
+    uint8_t *kind = reinterpret_cast<uint8_t *>(tile + (size_t)rows_pb * D);      // [D] 1: element of a categorical field
+    int *catf = reinterpret_cast<int *>(kind + ((D + 3) & ~3));                     // [C] the categorical fields
+    __shared__ int s_ncat;
+    if (threadIdx.x == 0) s_ncat = 0;
+    __syncthreads();
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        const uint8_t ic = is_cat[f];
+        if (ic) catf[atomicAdd(&s_ncat, 1)] = f;
+        for (int j = offsets[f]; j < offsets[f + 1]; ++j) kind[j] = ic;
+    }
+    __syncthreads();
+    const int ncat = s_ncat;
     const int64_t nblk = ceil_div64(rows, rows_pb);
+    const int cstep = (int)(blockDim.x % (unsigned)D);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t r0 = blk * rows_pb;
         const int nr = (int)((rows - r0 < rows_pb) ? rows - r0 : rows_pb);
@@ -220,22 +235,28 @@ __global__ void k_head_merge(const float *__restrict__ y, const float *__restric
             tile[i] = v;
         }
         __syncthreads();
-        for (int w = threadIdx.x; w < nr * C; w += blockDim.x) {
-            const int r = w / C, f = w - r * C;
+        for (int w = threadIdx.x; w < nr * ncat; w += blockDim.x) {
+            const int r = w / ncat, f = catf[w - r * ncat];
             const int a = offsets[f], b = offsets[f + 1];
             float *p = tile + r * D;
-            if (is_cat[f]) {
-                float mx = p[a];
-                for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
-                float s = 0.f;
-                for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
-                for (int j = a; j < b; ++j) p[j] = p[j] / s;
-            } else if (!MERGE) {
-                for (int j = a; j < b; ++j) p[j] = 1.f / (1.f + expf(-p[j]));
-            }
+            float mx = p[a];
+            for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
+            float s = 0.f;
+            for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
+            for (int j = a; j < b; ++j) p[j] = p[j] / s;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) out[base + i] = tile[i];
+        int col = threadIdx.x % D;                       // column of element i (the tile starts at a row start)
+        for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+            float v = tile[i];
+            if (!MERGE) {
+                const float sg = 1.f / (1.f + expf(-v));
+                v = kind[col] ? v : sg;
+            }
+            out[base + i] = v;
+            col += cstep;
+            if (col >= D) col -= D;
+        }
         __syncthreads();
     }
 }
@@ -267,7 +288,10 @@ __global__ void k_head_reverse(const float *__restrict__ y, const float *__restr
     }
     __syncthreads();
     const int ncat = s_ncat;
-    auto pred_of = [&](float v, int col) { return kind[col] ? v : 1.f / (1.f + expf(-v)); };
+    auto pred_of = [&](float v, int col) {           // (unconditional sigmoid + select: no divergent region per element)
+        const float sg = 1.f / (1.f + expf(-v));
+        return kind[col] ? v : sg;
+    };
     const int64_t nblk = ceil_div64(rows, rows_pb);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t r0 = blk * rows_pb;
@@ -355,12 +379,16 @@ extern "C" int ddg_head_reverse_step(const float *y, const float *x_t, const flo
     int rc = rev_coef(sh, T, t, k);
     if (rc) return rc;
     if (rows == 0) return DDG_OK;
-    int rows_pb = 8192 / D;
+    // rows per workgroup: ~16 KiB tiles, eight workgroups per CU (the phases of a tile are separated by barriers: other
+    // workgroups fill the gaps); DDG_HEAD_TILE=<floats> overrides (A/B)
+    static const int tile_floats = [] { const char *e = getenv("DDG_HEAD_TILE"); const int v = e ? atoi(e) : 4096; return v < 256 ? 256 : (v > 8192 ? 8192 : v); }();
+    int rows_pb = tile_floats / D;
+    if (rows_pb < 1) rows_pb = 8192 / D;
     if (rows_pb < 1) return DDG_E_UNSUPPORTED;
     if (rows_pb > 64) rows_pb = 64;
     const size_t lds = (size_t)rows_pb * D * sizeof(float) + ((D + 3) & ~3) + (size_t)C * sizeof(int);
     const int64_t nblk = ceil_div64(rows, rows_pb);
-    const int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    const int grid = (int)(nblk < 256 * 16 ? nblk : 256 * 16);
     k_head_reverse<<<grid, 256, lds, (hipStream_t)stream>>>(y, x_t, x, M, z, k, seed, stream_id, offsets, is_cat, C, out,
                                                             rows, D, rows_pb);
     DDG_CHECK_LAUNCH();
@@ -377,7 +405,7 @@ static int launch_head_merge(bool merge, const float *y, const float *x, const f
     if (rows_pb > 64) rows_pb = 64;
     // a minibatch (B = 128) would fill three workgroups: fewer rows per workgroup until about 512 of them exist
     if (rows < (int64_t)512 * rows_pb) rows_pb = (int)(rows / 512 > 1 ? rows / 512 : 1);
-    const size_t lds = (size_t)rows_pb * D * sizeof(float);
+    const size_t lds = (size_t)rows_pb * D * sizeof(float) + ((D + 3) & ~3) + (size_t)C * sizeof(int);
     int64_t nblk = ceil_div64(rows, rows_pb);
     int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
     if (merge)

@@ -13,6 +13,8 @@ from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
 import numpy as np
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -311,14 +313,25 @@ class GraphedSteps:
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.graphs = {}
         ops.set_stream_offset(self.counter)
+        GraphedSteps._owner = weakref.ref(self)          # whose counter the library holds
+
+    _owner = None
 
     def close(self):
-        """switches the stream offset off; the counter tensor must outlive every kernel that may read it"""
-        if self.counter is not None:
-            torch.cuda.current_stream().synchronize()
+        """switches the stream offset off -- unless a later instance has set its own counter since (an instance that
+        the garbage collector finalises at some arbitrary point must not pull the offset from under its successor);
+        the counter tensor must outlive every kernel that may read it"""
+        if self.counter is None:
+            return
+        ref = GraphedSteps._owner
+        holder = ref() if ref is not None else None
+        if holder is self or (ref is not None and holder is None):      # (a dead reference: the holder is being finalised)
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
             ops.set_stream_offset(None)
-            self.counter = None
-            self.graphs = {}
+            GraphedSteps._owner = None
+        self.counter = None
+        self.graphs = {}
 
     def __del__(self):
         try:
