@@ -26,6 +26,7 @@ struct LinArgs {
     const float *A, *A2;
     int in1;
     const float *W, *bias;
+    const _Float16 *Ws;        // W pre-split in two f16 halves, [out][in / 4][hi x 4 | lo x 4] (k_split_weights), or null
     const float *emb;
     const int64_t *t;
     int t_uniform;
@@ -416,7 +417,8 @@ __global__ __launch_bounds__(256, (RT == 1 ? 3 : 2)) void k_linear_split(LinArgs
 // stretch of code as the MFMAs of chunk c, and the two waves of a SIMD overlap one's VALU with the other's MFMAs.
 // Same products in the same order per output element as k_linear_split: bit-identical results.
 // ---------------------------------------------------------------------------------------------
-template <int PRO, int WR, int WC>
+// PS: the weights come pre-split (p.Ws): their staging is two 8-byte copies per float4 instead of a split.
+template <int PRO, int WR, int WC, bool PS>
 __global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
     static_assert(WR * WC == 8, "eight waves");
     constexpr int KCH = 32;
@@ -458,13 +460,27 @@ __global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
                 trows[i] = min(max(p.t ? (int)p.t[row] : p.t_uniform, 0), p.emb_rows - 1);
         }
 
-        f32x4 pa[NPA], pb[NPB];
+        f32x4 pa[NPA], pb[PS ? 1 : NPB];
+        f16x4 pbh[PS ? NPB : 1], pbl[PS ? NPB : 1];
         auto fetch = [&](int chunk) {
             const int k0 = chunk * KCH + st_c4 * 4;
 #pragma unroll
             for (int i = 0; i < NPA; ++i) pa[i] = lin_stage_a<PRO>(p, row0 + st_r + 64 * i, k0, trows[i], keep_scale, true);
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) pb[i] = lin_stage_b(p, col0 + st_r + 64 * i, k0, true);
+            for (int i = 0; i < NPB; ++i) {
+                if constexpr (PS) {
+                    const int n = col0 + st_r + 64 * i;
+                    pbh[i] = f16x4{0, 0, 0, 0};
+                    pbl[i] = f16x4{0, 0, 0, 0};
+                    if (n < p.out && k0 < p.in) {
+                        const f16x8 hl = *reinterpret_cast<const f16x8 *>(p.Ws + ((int64_t)n * p.in + k0) * 2);      // one 16-byte load
+                        pbh[i] = f16x4{hl[0], hl[1], hl[2], hl[3]};
+                        pbl[i] = f16x4{hl[4], hl[5], hl[6], hl[7]};
+                    }
+                } else {
+                    pb[i] = lin_stage_b(p, col0 + st_r + 64 * i, k0, true);
+                }
+            }
         };
         auto commit = [&](char *buf) {
             char *As = buf, *Bs = buf + BMW * SSTR;
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
                 const int rl = st_r + 64 * i;
-                split4(pb[i], hi, lo);
+                if constexpr (PS) { hi = pbh[i]; lo = pbl[i]; } else split4(pb[i], hi, lo);
                 *reinterpret_cast<f16x4 *>(&Bs[rl * SSTR + st_c4 * 8]) = hi;
                 *reinterpret_cast<f16x4 *>(&Bs[rl * SSTR + 2 * KCH + st_c4 * 8]) = lo;
             }
@@ -554,12 +570,24 @@ __global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
     }
 }
 
-template <int PRO, int WR, int WC>
+// W [out][in] fp32 -> f16 halves, interleaved per four elements: [out][in / 4][hi x 4 | lo x 4] (same split as split4; in % 4 == 0)
+__global__ void k_split_weights(const float *__restrict__ W, _Float16 *__restrict__ Ws, int out, int in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)out * in) return;
+    const int n = (int)(i / in), k = (int)(i - (int64_t)n * in);
+    const float v = W[i];
+    const _Float16 hh = (_Float16)v;
+    const int64_t o = ((int64_t)n * in + (k & ~3)) * 2 + (k & 3);
+    Ws[o] = hh;
+    Ws[o + 4] = (_Float16)((v - (float)hh) * SPLIT_LO_SCALE);
+}
+
+template <int PRO, int WR, int WC, bool PS>
 static int launch_wide(const LinArgs &p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (32 * WR + 96 * WC) * (4 * 32 + 16);
     static std::atomic<int> granted{0};
     if (!granted.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_linear_wide<PRO, WR, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_linear_wide<PRO, WR, WC, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             fprintf(stderr, "ddgani: hipFuncSetAttribute(%zu): %s\n", lds, hipGetErrorString(e));
             return DDG_E_LAUNCH;
@@ -572,7 +600,7 @@ static int launch_wide(const LinArgs &p, hipStream_t s) {
     const int64_t cap = (256 + ncol - 1) / ncol;            // one resident workgroup per CU
     if (g > cap) g = cap;
     if (g >= 8) g -= g % 8;
-    k_linear_wide<PRO, WR, WC><<<dim3((unsigned)g, (unsigned)ncol), 512, lds, s>>>(p);
+    k_linear_wide<PRO, WR, WC, PS><<<dim3((unsigned)g, (unsigned)ncol), 512, lds, s>>>(p);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
@@ -710,7 +738,9 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
         // wide column tiles (DDG_LINEAR_WIDE=0: the 128-column kernel, A/B)
         static const bool wide = [] { const char *e = getenv("DDG_LINEAR_WIDE"); return !(e && e[0] == '0'); }();
         if (fast && wide) {
-#define LAUNCH_WIDE(PRO_) return p.out <= 192 ? launch_wide<PRO_, 4, 2>(p, s) : launch_wide<PRO_, 2, 4>(p, s);
+#define LAUNCH_WIDE(PRO_)                                                                                          \
+            return p.Ws ? (p.out <= 192 ? launch_wide<PRO_, 4, 2, true>(p, s) : launch_wide<PRO_, 2, 4, true>(p, s))  \
+                        : (p.out <= 192 ? launch_wide<PRO_, 4, 2, false>(p, s) : launch_wide<PRO_, 2, 4, false>(p, s));
             switch (prologue) {
                 case DDG_PRO_NONE: LAUNCH_WIDE(DDG_PRO_NONE)
                 case DDG_PRO_ADD_EMB: LAUNCH_WIDE(DDG_PRO_ADD_EMB)
@@ -750,7 +780,8 @@ static int launch_linear(const LinArgs &p, int prologue, hipStream_t s) {
 static int linear_impl(const float *A, const float *A2, int in1, const float *W, const float *bias, int prologue,
                        const float *emb, int emb_rows, const int64_t *t, int t_uniform, const float *scale,
                        const float *shift, const uint8_t *drop, float drop_p, uint64_t seed, uint64_t stream_id, float *Y,
-                       double *stats, int64_t rows, int in, int out, void *stream) {
+                       double *stats, int64_t rows, int in, int out, void *stream, _Float16 *wsplit = nullptr) {
+    // wsplit: scratch of 2 * out * in f16 for the pre-split weights of the wide kernel, or null (split per tile)
     if (!A || !W || !bias || !Y || rows < 0 || in < 1 || out < 1) return DDG_E_ARG;
     if (A2 ? (in1 < 1 || in1 >= in) : (in1 != in)) return DDG_E_ARG;
     if ((prologue == DDG_PRO_ADD_EMB || prologue == DDG_PRO_EMB_RELU) && !emb) return DDG_E_ARG;
@@ -762,6 +793,12 @@ static int linear_impl(const float *A, const float *A2, int in1, const float *W,
     p.emb_rows = emb_rows < 1 ? 1 : emb_rows;
     p.scale = scale; p.shift = shift; p.drop = drop; p.drop_p = drop_p; p.seed = seed; p.stream_id = stream_id;
     p.Y = Y; p.stats = stats; p.rows = rows; p.in = in; p.out = out;
+    p.Ws = nullptr;
+    if (wsplit && rows >= SPLIT_MIN_ROWS && !A2 && (in & 3) == 0 && !linear_force_f32()) {
+        const int64_t n = (int64_t)out * in;
+        k_split_weights<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, wsplit, out, in);
+        p.Ws = wsplit;
+    }
     return launch_linear(p, prologue, (hipStream_t)stream);
 }
 
@@ -777,15 +814,19 @@ extern "C" int ddg_linear(const float *A, const float *A2, int in1, const float 
 // ---------------------------------------------------------------------------------------------
 // a6 Generator_x0.forward, single-GPU composition
 // workspace: z1 [rows,enc] | z2 [rows,lat] | stats double[2*max] x3 | scale/shift float[max] x 2 x 3
+//            | from SPLIT_MIN_ROWS rows: W1..W4 pre-split in f16 halves
 // (z3 reuses z1; the pre-head logits go straight to `out`)
 // ---------------------------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t ddg_denoiser_workspace_bytes(int64_t rows, int in_dim, int enc_dim, int lat_dim) {
-    (void)in_dim;
     const size_t mx = (size_t)(enc_dim > lat_dim ? enc_dim : lat_dim);
-    return align256((size_t)rows * enc_dim * 4) + align256((size_t)rows * lat_dim * 4) + 3 * align256(2 * mx * 8) +
-           6 * align256(mx * 4);
+    size_t b = align256((size_t)rows * enc_dim * 4) + align256((size_t)rows * lat_dim * 4) + 3 * align256(2 * mx * 8) +
+               6 * align256(mx * 4);
+    // full-table calls: the four weight matrices pre-split in f16 halves (4 bytes per element, as the fp32 originals)
+    if (rows >= SPLIT_MIN_ROWS)
+        b += 2 * align256((size_t)in_dim * enc_dim * 4) + 2 * align256((size_t)enc_dim * lat_dim * 4);
+    return b;
 }
 
 extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, const int64_t *t, int t_uniform,
@@ -806,29 +847,36 @@ extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, cons
     for (int i = 0; i < 3; ++i) { st[i] = (double *)p; p += align256(2 * mx * 8); }
     float *sc[3], *sh[3];
     for (int i = 0; i < 3; ++i) { sc[i] = (float *)p; p += align256(mx * 4); sh[i] = (float *)p; p += align256(mx * 4); }
+    _Float16 *ws4[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (rows >= SPLIT_MIN_ROWS) {
+        ws4[0] = (_Float16 *)p; p += align256((size_t)D * E * 4);
+        ws4[1] = (_Float16 *)p; p += align256((size_t)E * L * 4);
+        ws4[2] = (_Float16 *)p; p += align256((size_t)E * L * 4);
+        ws4[3] = (_Float16 *)p; p += align256((size_t)D * E * 4);
+    }
     if (hipMemsetAsync(st[0], 0, 3 * align256(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
     int rc;
     // layer 1: (x + temb[t]) W1^T + b1
     rc = linear_impl(x_t, nullptr, D, w->W1, w->b1, DDG_PRO_ADD_EMB, w->temb, w->n_steps, t, t_uniform, nullptr, nullptr, nullptr,
-                    0.f, 0, 0, z1, st[0], rows, D, E, stream);
+                    0.f, 0, 0, z1, st[0], rows, D, E, stream, ws4[0]);
     if (rc) return rc;
     rc = ddg_bn_finalize(st[0], w->g1, w->be1, (double)rows, bn_eps, sc[0], sh[0], E, stream);
     if (rc) return rc;
     // layer 2: drop(relu(bn(z1))) W2^T + b2
-    rc = ddg_linear(z1, nullptr, E, w->W2, w->b2, DDG_PRO_BN_RELU, nullptr, nullptr, 0, sc[0], sh[0], drop0, drop_p,
-                    seed, stream_id * 4 + 0, z2, st[1], rows, E, L, stream);
+    rc = linear_impl(z1, nullptr, E, w->W2, w->b2, DDG_PRO_BN_RELU, nullptr, 1, nullptr, 0, sc[0], sh[0], drop0, drop_p,
+                     seed, stream_id * 4 + 0, z2, st[1], rows, E, L, stream, ws4[1]);
     if (rc) return rc;
     rc = ddg_bn_finalize(st[1], w->g2, w->be2, (double)rows, bn_eps, sc[1], sh[1], L, stream);
     if (rc) return rc;
     // layer 3 (z3 overwrites z1: z1 is dead once layer 2 has been enqueued, same stream)
-    rc = ddg_linear(z2, nullptr, L, w->W3, w->b3, DDG_PRO_BN_RELU, nullptr, nullptr, 0, sc[1], sh[1], drop1, drop_p,
-                    seed, stream_id * 4 + 1, z1, st[2], rows, L, E, stream);
+    rc = linear_impl(z2, nullptr, L, w->W3, w->b3, DDG_PRO_BN_RELU, nullptr, 1, nullptr, 0, sc[1], sh[1], drop1, drop_p,
+                     seed, stream_id * 4 + 1, z1, st[2], rows, L, E, stream, ws4[2]);
     if (rc) return rc;
     rc = ddg_bn_finalize(st[2], w->g3, w->be3, (double)rows, bn_eps, sc[2], sh[2], E, stream);
     if (rc) return rc;
     // layer 4 -> logits
-    rc = ddg_linear(z1, nullptr, E, w->W4, w->b4, DDG_PRO_BN_RELU, nullptr, nullptr, 0, sc[2], sh[2], drop2, drop_p,
-                    seed, stream_id * 4 + 2, out, nullptr, rows, E, D, stream);
+    rc = linear_impl(z1, nullptr, E, w->W4, w->b4, DDG_PRO_BN_RELU, nullptr, 1, nullptr, 0, sc[2], sh[2], drop2, drop_p,
+                     seed, stream_id * 4 + 2, out, nullptr, rows, E, D, stream, ws4[3]);
     if (rc) return rc;
     if (apply_head) {
         if (!offsets || !is_cat || C < 1) return DDG_E_ARG;

@@ -373,9 +373,12 @@ class GraphedSteps:
 
 def _graph_steps(optimizer, rnd, comm, x, M, m_data, T, device, blocked=False):
     """the GraphedSteps of this training run, or None where the eager path applies (parity mode, several ranks, FD loss,
-    DDG_TRAIN_GRAPH=0)."""
+    and by default: DDG_TRAIN_GRAPH=1 opts in).  Opt-in because of an open defect: in about one run in
+    six of the hospital pipeline the reconstruction loss of one fixed step (epoch 18, step 1) comes out NaN under graph
+    replay -- the eager steps, 14 runs, never did; workspaces poisoned with NaN change nothing, so it is a timing matter
+    between replayed kernels that has not been found yet."""
     import os
-    if blocked or rnd.name != "chip" or (comm is not None and comm.on) or os.environ.get("DDG_TRAIN_GRAPH", "1") == "0":
+    if blocked or rnd.name != "chip" or (comm is not None and comm.on) or os.environ.get("DDG_TRAIN_GRAPH", "0") != "1":
         return None
     gs = getattr(rnd, "_graphs", None)
     if gs is None or not gs.same_data(x, M, m_data, T):
@@ -428,6 +431,10 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
         losses.append(l)
     if losses:
         ls = torch.stack(losses).double().cpu()
+        if __import__("os").environ.get("DDG_DEBUG_NAN") and bool(torch.isnan(ls).any()) and not getattr(rnd, "_nan_seen", False):
+            rnd._nan_seen = True
+            bad = torch.isnan(ls).any(dim=1).nonzero().flatten().tolist()
+            print("DEBUG_NAN G epoch", epoch, "first bad steps", bad[:4], "of", len(losses), "prev row", ls[max(bad[0] - 1, 0)].tolist(), "row", ls[bad[0]].tolist(), flush=True)
         total = float((ls[:, 0] * loss_weight["Res_weight"] + ls[:, 1] * loss_weight["G_D_weight"]).mean()) \
             + float(other_loss)
         if fd_losses:
@@ -467,6 +474,12 @@ def train_one_epoch_discriminator_noise_x(generator_x0, discriminator_noise_x, D
                                         timesteps, loss_scale=scale, **kw)
             optimizer.step()
         losses.append(l)
+    if __import__("os").environ.get("DDG_DEBUG_NAN") and losses and not getattr(rnd, "_nan_seen", False):
+        ls = torch.stack(losses).double().cpu().flatten()
+        if bool(torch.isnan(ls).any()):
+            rnd._nan_seen = True
+            bad = torch.isnan(ls).nonzero().flatten().tolist()
+            print("DEBUG_NAN D epoch", epoch, "first bad steps", bad[:4], "of", len(losses), "prev", ls[max(bad[0] - 1, 0)].item(), flush=True)
     return float(torch.stack(losses).double().mean().cpu()) * scale if losses else 0.0
 
 
@@ -548,6 +561,11 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
                 generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout,
                                                 seed=rnd.seed, sched_host=DS.host)
             code = ops.mask_merge(x, M_tensor, generator_data, generator_x.layout)      # :598, :606-615
+            if __import__("os").environ.get("DDG_DEBUG_NAN"):
+                wn = {k: bool(torch.isnan(v).any()) for k, v in generator_x.state_dict().items()}
+                print("DEBUG_NAN epoch", epoch, "gen nan", int(torch.isnan(generator_data).sum()), "code nan",
+                      int(torch.isnan(code).sum()), "x nan", int(torch.isnan(x).sum()), "weights nan", [k for k, v in wn.items() if v],
+                      flush=True)
             if scorer is not None:
                 cur_r, cur_m = scorer.score(code)
             else:

@@ -6,6 +6,7 @@ pointers of contiguous tensors to libddgani_hip.so on torch's current HIP stream
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -233,6 +234,8 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        if os.environ.get("DDG_DEBUG_POISON"):       # every float / double of a fresh workspace reads as NaN
+            ws.fill_(0xFF)
         _ws_cache[key] = ws
     return ws
 

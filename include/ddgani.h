@@ -173,7 +173,7 @@ int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, const int64_t *
  * workspace; the layer activations and BatchNorm sums live in a static device array of
  * DDG_STATIC_SCRATCH_BYTES that each GPU keeps until the process ends.  It allocates nothing.
  * rows is limited by ddg_denoiser_workspace_bytes(rows, in, enc, lat) <= DDG_STATIC_SCRATCH_BYTES
- * (about 15 800 rows at D = 176); larger inputs return DDG_E_SCRATCH_LIMIT.  All calls on one GPU
+ * (about 15 400 rows at D = 176); larger inputs return DDG_E_SCRATCH_LIMIT.  All calls on one GPU
  * share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.  The first
  * call on a device looks up the array's device address (hipGetSymbolAddress); make it outside a
  * graph capture.
