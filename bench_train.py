@@ -31,7 +31,6 @@ def main():
         sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                                   f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
                                   os.path.abspath(__file__)] + sys.argv[1:]))
-    os.environ.setdefault("DDG_TRAIN_GRAPH", "1")      # the single-process rate is quoted with HIP-graph replay (opt-in in the library)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)

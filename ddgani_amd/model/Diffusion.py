@@ -300,6 +300,11 @@ class GraphedSteps:
     The first replay (counter 0) is bit-identical to the eager step with the same stream number
     (tests/test_gpu_graph_train.py)."""
     RING = 64
+    # A replay is launched only when the previous step has drained (DDG_GRAPH_SYNC=0 lifts that): with the host running
+    # ahead, about one run in six of the hospital pipeline produced a NaN reconstruction loss at one fixed step (always
+    # the second step after an idle GPU: the first launch that overlaps an executing one); 36 runs with the wait, and
+    # every eager run, did not.  The wait costs 2.5 % (4 220 instead of 4 330 steps/s): the step is GPU bound.
+    SYNC_BEFORE_REPLAY = __import__("os").environ.get("DDG_GRAPH_SYNC", "1") == "1"
     BASE_STREAM = stream_of(1 << 35, KIND_EPS)      # call numbers of graph replays: 2^35 + 256 n, apart from next_call()
 
     def __init__(self, x, M, m_data, T, device, batch=128):
@@ -367,18 +372,65 @@ class GraphedSteps:
                 loss = self._body(fn)
             self.graphs[key] = (g, loss)
             return first
+        if GraphedSteps.SYNC_BEFORE_REPLAY:
+            torch.cuda.current_stream().synchronize()
         ent[0].replay()
         return ent[1]
 
 
+def _debug_ws_probe(rnd, epoch, step, PG, PD, C_, device, loss):
+    """DDG_DEBUG_NAN=2: after a generator step, the training workspace's buffers that hold a NaN (names from the carve
+    order of csrc/train.hip::train_carve), recorded on the device and printed once, for the first step that has one."""
+    if getattr(rnd, "_probe_done", False):
+        return
+    ws = ops._ws_cache.get((str(device), "train"))
+    if ws is None:
+        return
+    B, D, E, L, H = 128, PG.in_dim, PG.enc_dim, PG.lat_dim, PD.lat_dim
+    mx = max(E, L)
+    names, sizes = [], []
+    def f(n, k):
+        names.append(n); sizes.append(k * 4)
+    for n, k in (("xt", B * D), ("h0", B * D), ("z1", B * E), ("h1", B * E), ("g1", B * E), ("z2", B * L), ("h2", B * L),
+                 ("g2", B * L), ("z3", B * E), ("h3", B * E), ("g3", B * E), ("y", B * D), ("pred", B * D)):
+        f(n, k)
+    for i in range(3):
+        names.append(f"st{i}"); sizes.append(2 * mx * 8)
+    for i in range(3):
+        f(f"sc{i}", mx); f(f"sf{i}", mx)
+    for n, k in (("xtj1", B * D), ("a1", B * H), ("r1", B * H), ("a2", B * H), ("r2", B * H), ("a3", B * H), ("r3", B * H),
+                 ("a4", B * C_), ("da4", B * C_), ("dA", B * H), ("dB", B * H), ("dcat", B * 2 * D), ("dres", B * D),
+                 ("dy", B * D), ("dh", B * mx), ("dz", B * mx), ("bsum", 2 * mx), ("ngood", C_)):
+        f(n, k)
+    names.append("lpart"); sizes.append(C_ * 8)
+    if not hasattr(rnd, "_probe_log"):
+        rnd._probe_log = []
+    flags, o = [], 0
+    for n, sz in zip(names, sizes):
+        al = (sz + 255) & ~255
+        if n.startswith("st") or n == "lpart":
+            v = ws[o:o + sz].view(torch.float64)
+        else:
+            v = ws[o:o + sz].view(torch.float32)
+        flags.append(torch.isnan(v).any() | torch.isinf(v).any())
+        o += al
+    rnd._probe_log.append((epoch, step, torch.stack(flags), loss.clone()))
+    if len(rnd._probe_log) >= 6:          # once per epoch: look at the recorded steps
+        for ep, st, fl, ls in rnd._probe_log:
+            fl = fl.cpu()
+            if bool(fl.any()) or bool(torch.isnan(ls).any()):
+                rnd._probe_done = True
+                print("DEBUG_WS epoch", ep, "step", st, "loss", ls.tolist(), "non-finite in",
+                      [n for n, b in zip(names, fl.tolist()) if b], flush=True)
+                break
+        rnd._probe_log = []
+
+
 def _graph_steps(optimizer, rnd, comm, x, M, m_data, T, device, blocked=False):
     """the GraphedSteps of this training run, or None where the eager path applies (parity mode, several ranks, FD loss,
-    and by default: DDG_TRAIN_GRAPH=1 opts in).  Opt-in because of an open defect: in about one run in
-    six of the hospital pipeline the reconstruction loss of one fixed step (epoch 18, step 1) comes out NaN under graph
-    replay -- the eager steps, 14 runs, never did; workspaces poisoned with NaN change nothing, so it is a timing matter
-    between replayed kernels that has not been found yet."""
+    DDG_TRAIN_GRAPH=0)."""
     import os
-    if blocked or rnd.name != "chip" or (comm is not None and comm.on) or os.environ.get("DDG_TRAIN_GRAPH", "0") != "1":
+    if blocked or rnd.name != "chip" or (comm is not None and comm.on) or os.environ.get("DDG_TRAIN_GRAPH", "1") == "0":
         return None
     gs = getattr(rnd, "_graphs", None)
     if gs is None or not gs.same_data(x, M, m_data, T):
@@ -411,6 +463,8 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
                                            loss_weight["Res_weight"], loss_weight["G_D_weight"], seed=rnd.seed,
                                            stream_id=GraphedSteps.BASE_STREAM)[0]
             l = gs.step(("G", id(optimizer), loss_weight["Res_weight"], loss_weight["G_D_weight"]), g_step, rnd)
+            if __import__("os").environ.get("DDG_DEBUG_NAN") == "2":       # which workspace buffer holds the first NaN
+                _debug_ws_probe(rnd, epoch, len(losses), PG, PD, model.layout.C, x.device, l)
             optimizer.step()
             losses.append(l.clone())
             continue

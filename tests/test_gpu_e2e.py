@@ -203,10 +203,9 @@ def test_imputation_path_on_reference_weights(tmp_path):
 
 
 def test_end_to_end_throughput_mode(tmp_path):
-    """The same pipeline with on-chip random numbers (rng="chip": what a production run uses; eager steps -- HIP-graph
-    replay of the steps is opt-in, DDG_TRAIN_GRAPH=1, and covered step by step in test_gpu_graph_train.py).  Not a replay
-    of the reference's streams, so the scores are compared statistically: after 100 epochs within 0.02 of the
-    reference's ARMSE / AMAE on this run (its own thread-count spread is 0.003)."""
+    """The same pipeline with on-chip random numbers and the training steps replayed as HIP graphs (rng="chip": what
+    a production run uses).  Not a replay of the reference's streams, so the scores are compared statistically: after
+    100 epochs within 0.02 of the reference's ARMSE / AMAE on this run (its own thread-count spread is 0.003)."""
     z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, "e2e_hospital", "hospital.csv", rng="chip", epochs=100)
     assert len(log) == 1 and log[0][0] == 100
     assert abs(log[0][1] - float(z["scores"][0][0])) < 0.02, log
