@@ -157,6 +157,7 @@ typedef struct ddg_gen_weights {
     const float *temb;                          /* time_embedding.weight [n_steps,in]       */
 } ddg_gen_weights;
 
+/* (from 8 192 rows on the size includes room for the four weight matrices pre-split into f16 halves) */
 size_t ddg_denoiser_workspace_bytes(int64_t rows, int in_dim, int enc_dim, int lat_dim);
 /* drop0..2: explicit keep-masks uint8 [rows,enc],[rows,lat],[rows,enc] or NULL (on-chip RNG
  * when drop_p > 0).  apply_head == 0 leaves the pre-head logits in `out`. */
