@@ -328,6 +328,8 @@ class GraphedSteps:
         the counter tensor must outlive every kernel that may read it"""
         if self.counter is None:
             return
+        if hasattr(self, "maxin"):
+            print("DEBUG_OVERLAP max replays in flight", int(self.maxin.item()), "now", int(self.inflight.item()), flush=True)
         ref = GraphedSteps._owner
         holder = ref() if ref is not None else None
         if holder is self or (ref is not None and holder is None):      # (a dead reference: the holder is being finalised)
@@ -349,10 +351,19 @@ class GraphedSteps:
                                                                        self.m.data_ptr(), self.T)
 
     def _body(self, fn):
+        dbg = __import__("os").environ.get("DDG_DEBUG_NAN") == "3"     # do two replays ever overlap on the device?
+        if dbg:
+            if not hasattr(self, "inflight"):
+                self.inflight = torch.zeros(1, dtype=torch.int32, device=self.dev)
+                self.maxin = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.inflight.add_(1)
+            torch.maximum(self.maxin, self.inflight, out=self.maxin)
         idx, t = self.feed[:self.B], self.feed[self.B:]
         x0, Mb, mb = self.x.index_select(0, idx), self.M.index_select(0, idx), self.m.index_select(0, idx)
         loss = fn(x0, Mb, mb, t)
         self.counter.add_(1 << 32)
+        if dbg:
+            self.inflight.sub_(1)
         return loss
 
     def step(self, key, fn, rnd):
