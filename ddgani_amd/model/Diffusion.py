@@ -300,11 +300,10 @@ class GraphedSteps:
     The first replay (counter 0) is bit-identical to the eager step with the same stream number
     (tests/test_gpu_graph_train.py)."""
     RING = 64
-    # A replay is launched only when the previous step has drained (DDG_GRAPH_SYNC=0 lifts that): with the host running
-    # ahead, about one run in six of the hospital pipeline produced a NaN reconstruction loss at one fixed step (always
-    # the second step after an idle GPU: the first launch that overlaps an executing one); 36 runs with the wait, and
-    # every eager run, did not.  The wait costs 2.5 % (4 220 instead of 4 330 steps/s): the step is GPU bound.
-    SYNC_BEFORE_REPLAY = __import__("os").environ.get("DDG_GRAPH_SYNC", "1") == "1"
+    # DDG_GRAPH_SYNC=1: a replay is launched only when the previous step has drained (belt and braces for the defect
+    # described in step(): 36 clean runs with the wait alone, at -2.5 %); DDG_GRAPH_FEED=direct: the old feed path (unsafe)
+    SYNC_BEFORE_REPLAY = __import__("os").environ.get("DDG_GRAPH_SYNC", "0") == "1"
+    FEED_DIRECT = __import__("os").environ.get("DDG_GRAPH_FEED", "") == "direct"
     BASE_STREAM = stream_of(1 << 35, KIND_EPS)      # call numbers of graph replays: 2^35 + 256 n, apart from next_call()
 
     def __init__(self, x, M, m_data, T, device, batch=128):
@@ -313,6 +312,7 @@ class GraphedSteps:
         self.stage = torch.empty(self.RING, 2 * self.B, dtype=torch.int64).pin_memory()
         self.stage_np = self.stage.numpy()
         self.slot = 0
+        self.stage_dev = torch.zeros(self.RING, 2 * self.B, dtype=torch.int64, device=device)
         self.feed = torch.zeros(2 * self.B, dtype=torch.int64, device=device)       # [indices | timesteps]
         self.feed[self.B:] = 2
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
@@ -373,7 +373,16 @@ class GraphedSteps:
         row = self.stage_np[self.slot]
         row[:self.B] = rnd.gen.choice(self.x.shape[0], self.B, replace=False, shuffle=False)
         row[self.B:] = rnd.gen.integers(2, self.T + 1, size=self.B)
-        self.feed.copy_(self.stage[self.slot], non_blocking=True)
+        if GraphedSteps.FEED_DIRECT:
+            self.feed.copy_(self.stage[self.slot], non_blocking=True)
+        else:
+            # The host copy lands in a device slot of its own and a KERNEL moves it into the graph's static buffer.  A
+            # pinned-memory copy straight into that buffer is not held back until the executing replay has finished with
+            # it (the copy engine's order against a graph launch on the same stream): the step then reads indices and
+            # timesteps that change under it, and about one run in six of the hospital pipeline ended in NaN weights.
+            dslot = self.stage_dev[self.slot]
+            dslot.copy_(self.stage[self.slot], non_blocking=True)
+            self.feed.copy_(dslot)
         self.slot = (self.slot + 1) % self.RING
         ent = self.graphs.get(key)
         if ent is None:
