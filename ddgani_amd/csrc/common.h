@@ -19,6 +19,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline __host__ __device__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zeroing by a kernel of our own instead of hipMemsetAsync, in every entry point that callers capture into a HIP graph
+// (the training steps, the denoiser forward): a memset NODE of a replayed graph was observed to fill parts of the
+// BatchNorm sums with a non-zero garbage pattern about once in five runs of the hospital pipeline,
+// a kernel node of ours is ordered like every other kernel of the step.  bytes: a multiple of 16, p 16-byte aligned.
+static __global__ void k_zero16(uint4 *__restrict__ p, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static inline int zero_async(void *p, size_t bytes, hipStream_t s) {
+    if (((uintptr_t)p & 15) || (bytes & 15)) return DDG_E_ARG;
+    if (!bytes) return DDG_OK;
+    const size_t n16 = bytes / 16;
+    k_zero16<<<(unsigned)((n16 + 255) / 256), 256, 0, s>>>((uint4 *)p, n16);
+    return hipGetLastError() == hipSuccess ? DDG_OK : DDG_E_LAUNCH;
+}
+
+static __global__ void k_copy_f32(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+static inline int copy_f32_async(float *dst, const float *src, size_t n, hipStream_t s) {      // (a kernel, not a memcpy node)
+    if (!n) return DDG_OK;
+    k_copy_f32<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, dst, n);
+    return hipGetLastError() == hipSuccess ? DDG_OK : DDG_E_LAUNCH;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 counter-based generator (Salmon et al. 2011): one call -> 4 x uint32.
 // counter = (idx_lo, idx_hi, stream_lo, stream_hi), key = seed.

@@ -854,8 +854,8 @@ extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, cons
         ws4[2] = (_Float16 *)p; p += align256((size_t)E * L * 4);
         ws4[3] = (_Float16 *)p; p += align256((size_t)D * E * 4);
     }
-    if (hipMemsetAsync(st[0], 0, 3 * align256(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
-    int rc;
+    int rc = zero_async(st[0], 3 * align256(2 * mx * 8), s);      // not hipMemsetAsync: see common.h
+    if (rc) return rc;
     // layer 1: (x + temb[t]) W1^T + b1
     rc = linear_impl(x_t, nullptr, D, w->W1, w->b1, DDG_PRO_ADD_EMB, w->temb, w->n_steps, t, t_uniform, nullptr, nullptr, nullptr,
                     0.f, 0, 0, z1, st[0], rows, D, E, stream, ws4[0]);

@@ -472,9 +472,9 @@ __global__ void k_adam(AdamTable tb, float step_size, float one_m_b1, float b2, 
         // torch: exp_avg.lerp_(grad, 1-b1); exp_avg_sq.mul_(b2).addcmul_(grad, grad, 1-b2)
         const float mn = m[e] + one_m_b1 * (gg - m[e]);
         const float vn = v[e] * b2 + one_m_b2 * gg * gg;
+        const float denom = sqrtf(vn) / sqrt_bc2 + eps;
         m[e] = mn;
         v[e] = vn;
-        const float denom = sqrtf(vn) / sqrt_bc2 + eps;
         p[e] = p[e] - step_size * (mn / denom);
     }
 }
@@ -593,7 +593,7 @@ static int gen_forward_saved(const ddg_gen_weights *w, const ddg_train_batch *b,
     if (rc) return rc;
     k_add_emb<<<g256((int64_t)B * D), 256, 0, s>>>(ws.xt, w->temb, b->t, w->n_steps, B, D, ws.h0);
     const size_t mx = (size_t)(E > L ? E : L);
-    if (hipMemsetAsync(ws.st[0], 0, 3 * tal(2 * mx * 8), s) != hipSuccess) return DDG_E_LAUNCH;
+    if ((rc = zero_async(ws.st[0], 3 * tal(2 * mx * 8), s))) return rc;      // not hipMemsetAsync: see common.h
     const float *Wl[3] = {w->W1, w->W2, w->W3}, *bl[3] = {w->b1, w->b2, w->b3};
     const float *gl[3] = {w->g1, w->g2, w->g3}, *bel[3] = {w->be1, w->be2, w->be3};
     const uint8_t *dl[3] = {b->drop0, b->drop1, b->drop2};
@@ -716,9 +716,7 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
         if ((rc = gemm_dA(ws.dz, Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
     }
     k_emb_grad<<<dim3(gcol32(D), (unsigned)gw->n_steps), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
-    if (pred_out &&
-        hipMemcpyAsync(pred_out, ws.pred, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return DDG_E_LAUNCH;
+    if (pred_out && (rc = copy_f32_async(pred_out, ws.pred, (size_t)B * D, s))) return rc;
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
@@ -792,9 +790,7 @@ extern "C" int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc
     if ((rc = gemm_small(ws.dB, 1, H, ws.xtj1, D, 1, grads->W1, 2 * D, H, D, B, s))) return rc;
     if ((rc = gemm_small(ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B, s))) return rc;
     k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b1);
-    if (pred_out &&
-        hipMemcpyAsync(pred_out, ws.pred, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return DDG_E_LAUNCH;
+    if (pred_out && (rc = copy_f32_async(pred_out, ws.pred, (size_t)B * D, s))) return rc;
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }

@@ -293,46 +293,49 @@ def _train_batch(rnd, x, M, m_data, T, device, gen_widths, rank: int = 0):
 class GraphedSteps:
     """The generator and the discriminator minibatch step as HIP graphs (throughput mode, one process): a step is about
     45 short kernels whose launches, not their run time, set the pace.  Captured once per (network, loss scale): gather of
-    the batch rows from static index / timestep buffers, the gradient entry point, and the advance of a device counter
+    the batch rows from a static index / timestep buffer, the gradient entry point, and the advance of a device counter
     that the library adds to every random-stream number (ops.set_stream_offset) -- a graph freezes kernel arguments, so
-    the streams must move in device memory.  Per step the host draws the 128 row indices and timesteps, stages them
-    through a ring of pinned buffers, replays the graph and launches Adam (its bias corrections are host scalars).
-    The first replay (counter 0) is bit-identical to the eager step with the same stream number
-    (tests/test_gpu_graph_train.py)."""
+    the streams must move in device memory.  Per step the host draws the 128 row indices and timesteps into a ring of
+    pinned buffers, copies the slot into the static buffer (stream-ordered), replays the graph and launches Adam (its bias
+    corrections are host scalars).  A replay is bit-identical to the eager step with the same stream numbers, also over
+    hundreds of unsynchronised steps (tests/test_gpu_graph_train.py).
+
+    The word the library reads (``offset``) holds the replay counter only WHILE a step executes -- the first captured
+    kernel copies the counter into it, the last one clears it -- so every other on-chip draw on the device (the sampler
+    passes of the same run, another caller's (seed, stream_id)) sees an offset of zero and stays reproducible.  The
+    library holds ONE such pointer per device: a second live instance is refused.
+
+    Nothing inside the captured body may become a memset / memcpy NODE: the library zeroes and copies with kernels of its
+    own (csrc/common.h::zero_async), the bookkeeping here uses arithmetic kernels (DESIGN.md section 5 has the defect that
+    a ``hipMemsetAsync`` node caused)."""
     RING = 64
-    # DDG_GRAPH_SYNC=1: a replay is launched only when the previous step has drained (belt and braces for the defect
-    # described in step(): 36 clean runs with the wait alone, at -2.5 %); DDG_GRAPH_FEED=direct: the old feed path (unsafe)
-    SYNC_BEFORE_REPLAY = __import__("os").environ.get("DDG_GRAPH_SYNC", "0") == "1"
-    FEED_DIRECT = __import__("os").environ.get("DDG_GRAPH_FEED", "") == "direct"
     BASE_STREAM = stream_of(1 << 35, KIND_EPS)      # call numbers of graph replays: 2^35 + 256 n, apart from next_call()
+    _owner = None
 
     def __init__(self, x, M, m_data, T, device, batch=128):
+        live = GraphedSteps._owner() if GraphedSteps._owner is not None else None
+        if live is not None and live.counter is not None:
+            raise RuntimeError("a GraphedSteps instance already holds the device's stream offset: close() it first")
         self.x, self.M, self.m = x, M, m_data
         self.T, self.B, self.dev = T, min(batch, x.shape[0]), device
         self.stage = torch.empty(self.RING, 2 * self.B, dtype=torch.int64).pin_memory()
         self.stage_np = self.stage.numpy()
+        self.events = [None] * self.RING            # per slot: its last copy has run
         self.slot = 0
-        self.stage_dev = torch.zeros(self.RING, 2 * self.B, dtype=torch.int64, device=device)
         self.feed = torch.zeros(2 * self.B, dtype=torch.int64, device=device)       # [indices | timesteps]
         self.feed[self.B:] = 2
-        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)             # replays so far << 32
+        self.offset = torch.zeros(1, dtype=torch.int64, device=device)              # what the library adds: 0 outside a step
         self.graphs = {}
-        ops.set_stream_offset(self.counter)
-        GraphedSteps._owner = weakref.ref(self)          # whose counter the library holds
-
-    _owner = None
+        ops.set_stream_offset(self.offset)
+        GraphedSteps._owner = weakref.ref(self)
 
     def close(self):
-        """switches the stream offset off -- unless a later instance has set its own counter since (an instance that
-        the garbage collector finalises at some arbitrary point must not pull the offset from under its successor);
-        the counter tensor must outlive every kernel that may read it"""
+        """switches the stream offset off; the offset tensor must outlive every kernel that may read it"""
         if self.counter is None:
             return
-        if hasattr(self, "maxin"):
-            print("DEBUG_OVERLAP max replays in flight", int(self.maxin.item()), "now", int(self.inflight.item()), flush=True)
         ref = GraphedSteps._owner
-        holder = ref() if ref is not None else None
-        if holder is self or (ref is not None and holder is None):      # (a dead reference: the holder is being finalised)
+        if ref is not None and ref() in (self, None):
             if not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream().synchronize()
             ops.set_stream_offset(None)
@@ -351,38 +354,26 @@ class GraphedSteps:
                                                                        self.m.data_ptr(), self.T)
 
     def _body(self, fn):
-        dbg = __import__("os").environ.get("DDG_DEBUG_NAN") == "3"     # do two replays ever overlap on the device?
-        if dbg:
-            if not hasattr(self, "inflight"):
-                self.inflight = torch.zeros(1, dtype=torch.int32, device=self.dev)
-                self.maxin = torch.zeros(1, dtype=torch.int32, device=self.dev)
-            self.inflight.add_(1)
-            torch.maximum(self.maxin, self.inflight, out=self.maxin)
+        torch.add(self.counter, 0, out=self.offset)          # (arithmetic kernels: no memcpy / memset node in the graph)
         idx, t = self.feed[:self.B], self.feed[self.B:]
         x0, Mb, mb = self.x.index_select(0, idx), self.M.index_select(0, idx), self.m.index_select(0, idx)
         loss = fn(x0, Mb, mb, t)
         self.counter.add_(1 << 32)
-        if dbg:
-            self.inflight.sub_(1)
+        self.offset.mul_(0)
         return loss
 
     def step(self, key, fn, rnd):
         """fn(x0, Mb, mb, t) -> loss tensor, launching on the current stream with stream number BASE_STREAM."""
-        if self.slot == 0:
-            torch.cuda.current_stream().synchronize()        # the ring's copies of the last lap have run
+        ev = self.events[self.slot]
+        if ev is not None:
+            ev.synchronize()                                 # the slot's copy of the previous lap has run
         row = self.stage_np[self.slot]
         row[:self.B] = rnd.gen.choice(self.x.shape[0], self.B, replace=False, shuffle=False)
         row[self.B:] = rnd.gen.integers(2, self.T + 1, size=self.B)
-        if GraphedSteps.FEED_DIRECT:
-            self.feed.copy_(self.stage[self.slot], non_blocking=True)
-        else:
-            # The host copy lands in a device slot of its own and a KERNEL moves it into the graph's static buffer.  A
-            # pinned-memory copy straight into that buffer is not held back until the executing replay has finished with
-            # it (the copy engine's order against a graph launch on the same stream): the step then reads indices and
-            # timesteps that change under it, and about one run in six of the hospital pipeline ended in NaN weights.
-            dslot = self.stage_dev[self.slot]
-            dslot.copy_(self.stage[self.slot], non_blocking=True)
-            self.feed.copy_(dslot)
+        self.feed.copy_(self.stage[self.slot], non_blocking=True)
+        if ev is None:
+            ev = self.events[self.slot] = torch.cuda.Event()
+        ev.record()
         self.slot = (self.slot + 1) % self.RING
         ent = self.graphs.get(key)
         if ent is None:
@@ -392,58 +383,8 @@ class GraphedSteps:
                 loss = self._body(fn)
             self.graphs[key] = (g, loss)
             return first
-        if GraphedSteps.SYNC_BEFORE_REPLAY:
-            torch.cuda.current_stream().synchronize()
         ent[0].replay()
         return ent[1]
-
-
-def _debug_ws_probe(rnd, epoch, step, PG, PD, C_, device, loss):
-    """DDG_DEBUG_NAN=2: after a generator step, the training workspace's buffers that hold a NaN (names from the carve
-    order of csrc/train.hip::train_carve), recorded on the device and printed once, for the first step that has one."""
-    if getattr(rnd, "_probe_done", False):
-        return
-    ws = ops._ws_cache.get((str(device), "train"))
-    if ws is None:
-        return
-    B, D, E, L, H = 128, PG.in_dim, PG.enc_dim, PG.lat_dim, PD.lat_dim
-    mx = max(E, L)
-    names, sizes = [], []
-    def f(n, k):
-        names.append(n); sizes.append(k * 4)
-    for n, k in (("xt", B * D), ("h0", B * D), ("z1", B * E), ("h1", B * E), ("g1", B * E), ("z2", B * L), ("h2", B * L),
-                 ("g2", B * L), ("z3", B * E), ("h3", B * E), ("g3", B * E), ("y", B * D), ("pred", B * D)):
-        f(n, k)
-    for i in range(3):
-        names.append(f"st{i}"); sizes.append(2 * mx * 8)
-    for i in range(3):
-        f(f"sc{i}", mx); f(f"sf{i}", mx)
-    for n, k in (("xtj1", B * D), ("a1", B * H), ("r1", B * H), ("a2", B * H), ("r2", B * H), ("a3", B * H), ("r3", B * H),
-                 ("a4", B * C_), ("da4", B * C_), ("dA", B * H), ("dB", B * H), ("dcat", B * 2 * D), ("dres", B * D),
-                 ("dy", B * D), ("dh", B * mx), ("dz", B * mx), ("bsum", 2 * mx), ("ngood", C_)):
-        f(n, k)
-    names.append("lpart"); sizes.append(C_ * 8)
-    if not hasattr(rnd, "_probe_log"):
-        rnd._probe_log = []
-    flags, o = [], 0
-    for n, sz in zip(names, sizes):
-        al = (sz + 255) & ~255
-        if n.startswith("st") or n == "lpart":
-            v = ws[o:o + sz].view(torch.float64)
-        else:
-            v = ws[o:o + sz].view(torch.float32)
-        flags.append(torch.isnan(v).any() | torch.isinf(v).any())
-        o += al
-    rnd._probe_log.append((epoch, step, torch.stack(flags), loss.clone()))
-    if len(rnd._probe_log) >= 6:          # once per epoch: look at the recorded steps
-        for ep, st, fl, ls in rnd._probe_log:
-            fl = fl.cpu()
-            if bool(fl.any()) or bool(torch.isnan(ls).any()):
-                rnd._probe_done = True
-                print("DEBUG_WS epoch", ep, "step", st, "loss", ls.tolist(), "non-finite in",
-                      [n for n, b in zip(names, fl.tolist()) if b], flush=True)
-                break
-        rnd._probe_log = []
 
 
 def _graph_steps(optimizer, rnd, comm, x, M, m_data, T, device, blocked=False):
@@ -483,8 +424,6 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
                                            loss_weight["Res_weight"], loss_weight["G_D_weight"], seed=rnd.seed,
                                            stream_id=GraphedSteps.BASE_STREAM)[0]
             l = gs.step(("G", id(optimizer), loss_weight["Res_weight"], loss_weight["G_D_weight"]), g_step, rnd)
-            if __import__("os").environ.get("DDG_DEBUG_NAN") == "2":       # which workspace buffer holds the first NaN
-                _debug_ws_probe(rnd, epoch, len(losses), PG, PD, model.layout.C, x.device, l)
             optimizer.step()
             losses.append(l.clone())
             continue
@@ -505,10 +444,6 @@ def train_one_epoch_Generator(model, discriminator_noise_x, DS, x, optimizer, lo
         losses.append(l)
     if losses:
         ls = torch.stack(losses).double().cpu()
-        if __import__("os").environ.get("DDG_DEBUG_NAN") and bool(torch.isnan(ls).any()) and not getattr(rnd, "_nan_seen", False):
-            rnd._nan_seen = True
-            bad = torch.isnan(ls).any(dim=1).nonzero().flatten().tolist()
-            print("DEBUG_NAN G epoch", epoch, "first bad steps", bad[:4], "of", len(losses), "prev row", ls[max(bad[0] - 1, 0)].tolist(), "row", ls[bad[0]].tolist(), flush=True)
         total = float((ls[:, 0] * loss_weight["Res_weight"] + ls[:, 1] * loss_weight["G_D_weight"]).mean()) \
             + float(other_loss)
         if fd_losses:
@@ -548,12 +483,6 @@ def train_one_epoch_discriminator_noise_x(generator_x0, discriminator_noise_x, D
                                         timesteps, loss_scale=scale, **kw)
             optimizer.step()
         losses.append(l)
-    if __import__("os").environ.get("DDG_DEBUG_NAN") and losses and not getattr(rnd, "_nan_seen", False):
-        ls = torch.stack(losses).double().cpu().flatten()
-        if bool(torch.isnan(ls).any()):
-            rnd._nan_seen = True
-            bad = torch.isnan(ls).nonzero().flatten().tolist()
-            print("DEBUG_NAN D epoch", epoch, "first bad steps", bad[:4], "of", len(losses), "prev", ls[max(bad[0] - 1, 0)].item(), flush=True)
     return float(torch.stack(losses).double().mean().cpu()) * scale if losses else 0.0
 
 
@@ -617,49 +546,46 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
         scorer = DeviceScorer(fields, value_cat, values, ori_data, data_m, enc, continuous_cols, dev)
     except ValueError:
         scorer = None
-    for epoch in range(1, epochs + 1):
-        other_loss = L_loss * loss_weight["L_weight"]
-        train_one_epoch_Generator(generator_x, discriminator_noise_x, DS, x, optG, None, other_loss, epoch, epochs,
-                                  num_steps, dev, fields, M_tensor, m_data, loss_weight, FDs_model_list, fields,
-                                  zero_feed_data, rnd=rnd)
-        train_one_epoch_discriminator_noise_x(generator_x, discriminator_noise_x, DS, x, optD, None, other_loss, epoch,
-                                              epochs, num_steps, dev, fields, M_tensor, m_data, loss_weight, rnd=rnd)
-        if epoch_hook is not None:
-            epoch_hook(epoch, generator_x, discriminator_noise_x, valid_data_index)
-        if epoch % sample_every == 0:
-            if rng == "host":
-                rand, eps2 = host_sampler_randomness(rnd, num_steps, no, dim, widths, dev)
-                generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout, randomness=rand,
-                                                sched_host=DS.host)
-            else:
-                generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout,
-                                                seed=rnd.seed, sched_host=DS.host)
-            code = ops.mask_merge(x, M_tensor, generator_data, generator_x.layout)      # :598, :606-615
-            if __import__("os").environ.get("DDG_DEBUG_NAN"):
-                wn = {k: bool(torch.isnan(v).any()) for k, v in generator_x.state_dict().items()}
-                print("DEBUG_NAN epoch", epoch, "gen nan", int(torch.isnan(generator_data).sum()), "code nan",
-                      int(torch.isnan(code).sum()), "x nan", int(torch.isnan(x).sum()), "weights nan", [k for k, v in wn.items() if v],
-                      flush=True)
-            if scorer is not None:
-                cur_r, cur_m = scorer.score(code)
-            else:
-                cur_r, cur_m = test_impute_data_rmse(code, fields, value_cat, values, miss_data_x.copy(), data_m, enc,
-                                                     ori_data, continuous_cols)
-            if log is not None:
-                log.append((epoch, float(cur_r), float(cur_m)))
-            if use_Learner == 'True':
-                L_loss, acc = train_L_code(1000, code[tidx], label_data_code[tidx], x_valid, y_valid, label_num, dev)
-                L_loss = float(L_loss)
-            else:
-                L_loss = 0
-            if cur_r < r_M:
-                impute_data = pd.DataFrame(reconvert_data(code, fields, value_cat, values, miss_data_x.copy(), data_m,
-                                                          enc))
-                impute_data.columns = values
-                b_e, r_M = epoch, cur_r
+    try:
+        for epoch in range(1, epochs + 1):
+            other_loss = L_loss * loss_weight["L_weight"]
+            train_one_epoch_Generator(generator_x, discriminator_noise_x, DS, x, optG, None, other_loss, epoch, epochs,
+                                      num_steps, dev, fields, M_tensor, m_data, loss_weight, FDs_model_list, fields,
+                                      zero_feed_data, rnd=rnd)
+            train_one_epoch_discriminator_noise_x(generator_x, discriminator_noise_x, DS, x, optD, None, other_loss, epoch,
+                                                  epochs, num_steps, dev, fields, M_tensor, m_data, loss_weight, rnd=rnd)
+            if epoch_hook is not None:
+                epoch_hook(epoch, generator_x, discriminator_noise_x, valid_data_index)
+            if epoch % sample_every == 0:
+                if rng == "host":
+                    rand, eps2 = host_sampler_randomness(rnd, num_steps, no, dim, widths, dev)
+                    generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout, randomness=rand,
+                                                    sched_host=DS.host)
+                else:
+                    generator_data = reverse_sample(optG.P, num_steps, x, M_tensor, generator_x.layout,
+                                                    seed=rnd.seed, sched_host=DS.host)
+                code = ops.mask_merge(x, M_tensor, generator_data, generator_x.layout)      # :598, :606-615
+                if scorer is not None:
+                    cur_r, cur_m = scorer.score(code)
+                else:
+                    cur_r, cur_m = test_impute_data_rmse(code, fields, value_cat, values, miss_data_x.copy(), data_m, enc,
+                                                         ori_data, continuous_cols)
+                if log is not None:
+                    log.append((epoch, float(cur_r), float(cur_m)))
+                if use_Learner == 'True':
+                    L_loss, acc = train_L_code(1000, code[tidx], label_data_code[tidx], x_valid, y_valid, label_num, dev)
+                    L_loss = float(L_loss)
+                else:
+                    L_loss = 0
+                if cur_r < r_M:
+                    impute_data = pd.DataFrame(reconvert_data(code, fields, value_cat, values, miss_data_x.copy(), data_m,
+                                                              enc))
+                    impute_data.columns = values
+                    b_e, r_M = epoch, cur_r
+    finally:
+        gsteps = getattr(rnd, "_graphs", None)
+        if gsteps is not None:       # graphed training steps: the library must not keep a pointer to their offset word
+            gsteps.close()
+            rnd._graphs = None
     print(b_e)
-    gsteps = getattr(rnd, "_graphs", None)
-    if gsteps is not None:       # graphed training steps: the library must not keep a pointer to their counter
-        gsteps.close()
-        rnd._graphs = None
     return impute_data.values
