@@ -118,6 +118,9 @@ SIGNATURES = {
                                    C.c_void_p]),
     "ddg_attn_select": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, c_f32p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_attn_fallback_pairs": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
+    "ddg_attn_set_key_chunk": (C.c_int, [C.c_int64]),
     "ddg_attn_fill": (C.c_int, [C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int,
                                 C.c_int, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddg_fd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),

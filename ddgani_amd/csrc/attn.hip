@@ -46,7 +46,8 @@ enum { MODE_TOPK = 0, MODE_HIST = 1, MODE_FILL = 2, MODE_WIN = 3, MODE_WFILL = 4
 // above that bin while listing the bin's own keys (<= WIN_CAP) for an exact in-list selection (k_attn_wlist).
 // Two full similarity passes instead of the radix path's six; pairs whose bracket misses go through the radix path.
 enum { WIN_MINMAX = 0, WIN_SHIST = 1, WIN_FULL = 2 };
-#define WIN_SAMPLE 8192      // sampled keys per column (stride = nk / WIN_SAMPLE)
+#define WIN_SAMPLE 8192      // sampled keys per column at least (stride = nk / sample size, win_kstride below)
+#define WIN_BIN_KEYS 2212.f  // sample size = (nk sqrt(q (1 - q)) / WIN_BIN_KEYS)^2: about 450 keys in a bin of the full pass
 #define WIN_CAP 1024         // listed keys per pair
 #define WIN_GROUP 4096       // workgroups per launch group of the second full pass (bounds the lists)
 #define WIN_SIGMAS 6.f       // half width of the sample bracket in standard deviations of the sample rank
@@ -101,6 +102,21 @@ struct AttnArgs {
     int wcap;                  // list capacity in use (<= WIN_CAP; tests shrink it to force the radix fallback)
 };
 
+// Stride of the sample passes over a column's key list.  The bracket the sample yields spans the sample ranks
+// q S -+ (WIN_SIGMAS sqrt(S q (1 - q)) + 3), q = k / nk, i.e. a fraction ~ 12 sqrt(q (1 - q) / S) of the nk keys, which
+// the full pass resolves into WBINS bins; the bin that holds the k-th largest logit is listed (<= WIN_CAP entries).  A fixed
+// S = 8192 keeps ~ 5.5e-4 nk keys per bin: fine at 1M rows (440), past the list capacity from ~ 2M valid keys on (c4 has
+// 5M).  So S grows with nk^2: keys per bin = 12 nk sqrt(q (1 - q)) / (WBINS sqrt(S)) stays near 450, and the three sample
+// passes cost 3 S / nk of a full pass (c4 at top_k = 0.05: S = 460k of 5M keys, 28 %).
+__device__ __forceinline__ int win_kstride(int nk_all, int k) {
+    if (nk_all < 2 * WIN_SAMPLE) return 1;
+    const float q = fminf((float)k / (float)nk_all, 1.f);
+    const float r = (float)nk_all * sqrtf(q * (1.f - q)) * (1.f / WIN_BIN_KEYS);
+    const float S = fmaxf(r * r, (float)WIN_SAMPLE);
+    const int st = (int)((float)nk_all / S);
+    return st < 1 ? 1 : st;
+}
+
 __device__ __forceinline__ uint32_t f2key(float v) {
     uint32_t u = __float_as_uint(v + 0.f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -113,6 +129,12 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __device__ __forceinline__ int level_shift(int L) { return L < 4 ? 25 - 7 * L : 0; }
 __device__ __forceinline__ int level_bits(int L) { return L < 4 ? 7 : 4; }
 
+// Instrumentation builds (FILT_TIMING: s_memtime sums, FILT_STATS: event counters; neither changes a result) must be
+// asked for with -DDDG_EXPERIMENTS as well, so that no such switch slips into a product build; the ablations that
+// produced wrong results on purpose (timing of a loop without its loads / epilogue / survivor path) are gone.
+#if (defined(FILT_TIMING) || defined(FILT_STATS)) && !defined(DDG_EXPERIMENTS)
+#error "FILT_TIMING / FILT_STATS are instrumentation builds: add -DDDG_EXPERIMENTS"
+#endif
 #ifdef FILT_TIMING
 __device__ unsigned long long g_filt_time[8];      // experiments only: s_memtime sums per wave of k_attn_screen
 extern "C" int ddg_debug_filt_time(unsigned long long *out8, int reset) {
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     const int c = s_col;
     const int nk_all = p.nk[c];
     // sample passes stream every kstride-th position of the key list
-    const int kstride = (MODE == MODE_WIN && p.sample && nk_all >= 2 * WIN_SAMPLE) ? nk_all / WIN_SAMPLE : 1;
+    const int kstride = (MODE == MODE_WIN && p.sample) ? win_kstride(nk_all, p.k) : 1;
     const int nk = (nk_all + kstride - 1) / kstride;
     const int32_t *kl = p.klist + (int64_t)c * p.Nk;
     const int off_c = p.offsets[c];
@@ -394,6 +416,58 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         }
     }
 
+    // ---- two-level accumulation of the fill sums (MODE_WFILL, MODE_FILL).  A lane adds up to nk / 2 weights of 0.95 .. 1
+    // one after the other; once the running sum passes ~ 1e5 its ulp is no longer small against the SPREAD of the addends
+    // and round-to-nearest stops being unbiased: measured +3e-4 (k = 320 000) to +1e-3 (k = 640 000) relative error of the
+    // weight sum Z, i.e. of every filled value, against 1e-7 for a pairwise fp32 sum (the reference's GEMM).  So the registers
+    // (and the LDS rows of wide column blocks) only hold the sums of FLUSH_TILES tiles; they are then added to a second level
+    // -- out_code itself and zab / a register for Z -- whose addends vary by far more than its ulp.
+    // Key lists below 65 536 entries keep ONE level (their sums stay far below the biased regime, and a changed summation
+    // order would move the exactly tied categorical votes of small tables, whose arg-max the reference's rounding decides:
+    // tests/test_gpu_e2e.py pins those).
+    constexpr int FLUSH_TILES = 8;
+    const bool two_level = nk >= 65536;
+    float Z2 = 0.f;                                           // MODE_FILL: second level of Z
+    if constexpr (MODE == MODE_WFILL || MODE == MODE_FILL) {
+        const bool on = (MODE == MODE_WFILL) ? active : qrow >= 0;
+        if (h == 0 && on) {
+            for (int e = 0; e < d_c; ++e) p.out_code[(int64_t)qrow * p.D + off_c + e] = 0.f;
+            if (MODE == MODE_WFILL) p.zab[slot] = 0.f;
+        }
+    }
+    auto flush = [&](auto onec) {
+        constexpr bool ONE = decltype(onec)::value;            // only accr[0] / acc1 is live
+        if constexpr (MODE == MODE_WFILL || MODE == MODE_FILL) {
+            const bool on = h == 0 && ((MODE == MODE_WFILL) ? active : qrow >= 0);
+            float *dst = p.out_code + (int64_t)(qrow < 0 ? 0 : qrow) * p.D + off_c;
+            if (MODE == MODE_FILL ? d_c == 1 : d_c <= 8) {
+#pragma unroll
+                for (int e = 0; e < (ONE || MODE == MODE_FILL ? 1 : 8); ++e) {
+                    float &r = (MODE == MODE_FILL) ? acc1 : accr[e];
+                    const float a = r + __shfl_xor(r, 32);
+                    if (on && e < d_c) dst[e] += a;
+                    r = 0.f;
+                }
+            } else {
+                float *accb = extra + (MODE == MODE_WFILL ? QPB + XOFF : 0) + (int64_t)tid * p.dcs;
+                __syncthreads();
+                if (on) {
+                    const float *a1 = accb + (int64_t)32 * p.dcs;
+                    for (int e = 0; e < d_c; ++e) dst[e] += accb[e] + a1[e];
+                }
+                __syncthreads();
+                for (int e = 0; e < d_c; ++e) accb[e] = 0.f;
+            }
+            if constexpr (MODE == MODE_WFILL) {
+                const float Zt = Z + __shfl_xor(Z, 32);
+                if (on) p.zab[slot] += Zt;
+            } else {
+                Z2 += Z;
+            }
+            Z = 0.f;
+        }
+    };
+
     // ---- key streaming
     const int st_row = tid >> 3, st_c = tid & 7;
     f32x4 pf[NPF];
@@ -402,22 +476,16 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     float *xs0 = extra + QPB, *xs1 = extra + QPB + 256;       // (a third one follows: pipelined loop)
     const float *ksrc = SPLIT ? reinterpret_cast<const float *>(p.Xks) : p.Xkp;     // rows of DP * 4 bytes either way
     auto prefetch = [&](int t) {
-#ifdef EXP_NOLOAD      // timing experiments only (wrong results): every tile re-reads the first rows
-        const int pos = (t & 1) * TK + st_row;
-#else
         const int pos = t * TK + st_row;
-#endif
         const int kidx = pos < nk ? kl[(int64_t)pos * kstride] : -1;
         const float *src = ksrc + (int64_t)(kidx < 0 ? 0 : kidx) * DP + st_c * 4;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             pf[i] = *reinterpret_cast<const f32x4 *>(src + 32 * i);      // rows past the list: zeroed at commit time, so that
         }                                                                //   nothing waits for the loads here
-#ifndef EXP_NOPFX
         pfx_ok = kidx >= 0;
         // unconditional load (clamped address): a predicated one makes the compiler wait for it right here
         if (SPLIT && MODE == MODE_WFILL) pfx = p.Xkp[(int64_t)(kidx < 0 ? 0 : kidx) * DP + off_c + (st_c < d_c ? st_c : 0)];
-#endif
     };
     auto commit = [&](float *buf, float *xsd) {
         float *dst = buf + st_row * LSTR + st_c * 4;
@@ -465,11 +533,6 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         const int rem = nk - t * TK;          // valid key rows in this tile (>= 1)
         const bool full = rem >= TK;
 
-#ifdef EXP_NOEPI       // timing experiments only (wrong results): no per-logit work
-        if (MODE == EXP_NOEPI) {
-            smax = fmaxf(smax, acc[0] + acc[5] + acc[15]);
-        } else
-#endif
         if constexpr (MODE == MODE_TOPK) {
             float thr = lst[KCAP - 1];
 #pragma unroll
@@ -806,6 +869,9 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                             }
                         }
                     }
+                    if constexpr (MODE == MODE_WFILL) {
+                        if (two_level && (t & (FLUSH_TILES - 1)) == FLUSH_TILES - 1) flush(onec);
+                    }
                     side_commit(xs0 + x_new);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+2 are in LDS
                     __syncthreads();
@@ -831,6 +897,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             if (t + 1 < ntk) prefetch(t + 1);
             f32x16 acc = mma(cur);
             epi(acc, t, cur, (t & 1) ? xs1 : xs0);
+            if (two_level && (t & (FLUSH_TILES - 1)) == FLUSH_TILES - 1) flush(std::false_type{});
             if (t + 1 < ntk) commit(nxt, (t & 1) ? xs0 : xs1);
             __syncthreads();
         }
@@ -915,27 +982,11 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
         }
     } else if (MODE == MODE_WFILL) {
         int *lcur = reinterpret_cast<int *>(extra);
-        const float Zt = Z + __shfl_xor(Z, 32);
-        // un-normalised sums of everything above the selected bin; k_attn_wlist adds the bin's kept keys and divides
-        if (d_c <= 8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = accr[e] + __shfl_xor(accr[e], 32);
-                if (h == 0 && active && e < d_c) p.out_code[(int64_t)qrow * p.D + off_c + e] = a;
-            }
-        } else {
-            __syncthreads();
-            if (h == 0 && active) {
-                const float *a0 = extra + QPB + XOFF + (int64_t)tid * p.dcs;
-                const float *a1 = extra + QPB + XOFF + (int64_t)(tid + 32) * p.dcs;
-                for (int e = 0; e < d_c; ++e) p.out_code[(int64_t)qrow * p.D + off_c + e] = a0[e] + a1[e];
-            }
-        }
+        // un-normalised sums of everything above the selected bin, in out_code / zab: the last partial level joins them
+        // here; k_attn_wlist adds the bin's kept keys and divides
+        flush(std::false_type{});
         __syncthreads();
-        if (h == 0 && active) {
-            p.zab[slot] = Zt;
-            p.nab[slot] = lcur[wid * 32 + r32];
-        }
+        if (h == 0 && active) p.nab[slot] = lcur[wid * 32 + r32];
     } else if (MODE == MODE_HIST) {
         smax = fmaxf(smax, __shfl_xor(smax, 32));
         if (p.level == 0 && h == 0) p.smax[slot] = smax;
@@ -963,19 +1014,13 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             if (p.level == 4) p.tau[sl] = (r > 0) ? key2f(pre) : -INFINITY;
         }
     } else {
-        const float Zt = Z + __shfl_xor(Z, 32);
-        if (d_c == 1) {
-            const float a = acc1 + __shfl_xor(acc1, 32);
-            if (h == 0 && qrow >= 0) p.out_code[(int64_t)qrow * p.D + off_c] = (Zt > 0.f) ? a / Zt : 0.f;
-        } else {
-            __syncthreads();
-            if (h == 0 && qrow >= 0) {
-                const float *a0 = extra + (int64_t)tid * p.dcs;
-                const float *a1 = extra + (int64_t)(tid + 32) * p.dcs;
-                for (int e = 0; e < d_c; ++e)
-                    p.out_code[(int64_t)qrow * p.D + off_c + e] = (Zt > 0.f) ? (a0[e] + a1[e]) / Zt : 0.f;
+        flush(std::false_type{});
+        const float Zt = Z2 + __shfl_xor(Z2, 32);
+        if (h == 0 && qrow >= 0)
+            for (int e = 0; e < d_c; ++e) {
+                float *dst = p.out_code + (int64_t)qrow * p.D + off_c + e;
+                *dst = (Zt > 0.f) ? *dst / Zt : 0.f;
             }
-        }
         if (h == 0 && qrow >= 0) {
             if (p.out_tau) p.out_tau[(int64_t)qrow * p.C + c] = tau;
             if (p.out_nvalid) p.out_nvalid[(int64_t)qrow * p.C + c] = nk;
@@ -1341,9 +1386,6 @@ __global__ __launch_bounds__(FILT_NT / QW, ((QW == 1 || (SCREEN_HALF && !SCREEN_
     // as ONE word per lane and tile.  k_attn_rescore unpacks the words (and drops the padding rows past the
     // end of the chunk, which hold copies of its last key).
     auto collect = [&](const f32x16 &acc, int tile, int qs) {
-#ifdef FILT_NOCOLLECT      // timing experiments only (wrong results): what this path costs
-        ++ncand[qs]; return;
-#endif
         // bit g = sign of (threshold - logit g): one subtract and one v_alignbit per logit, no compare / select
         // chain through vcc (logit 15 first, so that logit g ends at bit g)
         unsigned cm = 0;
@@ -2098,17 +2140,18 @@ struct AttnWs {
 // prefix before it yields about k+1 candidates per query; the cap keeps a chunk's bf16 rows inside the
 // Infinity Cache.  DDG_FILT_CHUNK (multiple of 128) forces a fixed chunk length: tests use a small one.
 #define FILT_CHUNK_MAX 262144       // <= 65536 tiles of 32 keys: the tile number of a candidate word has 16 bits
-// The environment is read ONCE per process (production calls never touch getenv again); DDG_FILT_CHUNK_RELOAD=1, set
-// before the first call, makes every call re-read it (the parity tests switch schedules inside one process).
-static int64_t filt_chunk_parse() {
-    const char *e = getenv("DDG_FILT_CHUNK");
-    const int64_t c = e ? atoll(e) : 0;
-    return c <= 0 ? 0 : (c < 128 ? 128 : (c / 128) * 128);
-}
+// DDG_FILT_CHUNK in the environment is read ONCE per process (production calls never touch getenv again);
+// ddg_attn_set_key_chunk overrides it from code (the parity tests switch schedules inside one process).
+static int64_t filt_chunk_round(int64_t c) { return c <= 0 ? 0 : (c < 128 ? 128 : (c / 128) * 128); }
+static std::atomic<int64_t> g_chunk_override{-1};
 static int64_t filt_chunk_fixed() {
-    static const bool reload = [] { const char *e = getenv("DDG_FILT_CHUNK_RELOAD"); return e && e[0] == '1'; }();
-    static const int64_t once = filt_chunk_parse();
-    return reload ? filt_chunk_parse() : once;
+    static const int64_t once = [] { const char *e = getenv("DDG_FILT_CHUNK"); return filt_chunk_round(e ? atoll(e) : 0); }();
+    const int64_t o = g_chunk_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : once;
+}
+extern "C" int ddg_attn_set_key_chunk(int64_t positions) {
+    g_chunk_override.store(positions < 0 ? -1 : filt_chunk_round(positions), std::memory_order_relaxed);
+    return DDG_OK;
 }
 
 // DDG_ATTN_RADIX=1: k > DDG_MAX_TOPK_REG goes through the 5-level radix select (six full passes) as in round 1;
@@ -2572,6 +2615,29 @@ extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk
     attn_args(a, w, *open, Nk, C, D, kk);
     a.out_code = out_code;
     return dispatch_fill(a, nb128, dcmax, D, s);
+}
+
+// How many pairs the last ddg_attn_fill on this workspace sent to its exact fp32 fallback (window path: bracket missed or
+// bin above the list capacity; register paths: ties longer than the list / candidate-slot overflow): the sum of the
+// compacted list's per-column counts, written to out_count_dev[0] on the stream.
+__global__ void k_sum_counts(const int32_t *__restrict__ cnt, int C, int32_t *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int s = 0;
+        for (int c = 0; c < C; ++c) s += cnt[c];
+        out[0] = s;
+    }
+}
+extern "C" int ddg_attn_fallback_pairs(int64_t Nq, int64_t Nk, int C, int D, int64_t k, int queries_alias_keys,
+                                       int32_t *out_count_dev, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!out_count_dev || k < 1) return DDG_E_ARG;
+    int rc = attn_check_dims(Nq, Nk, C, D, DDG_ATTN_F32);
+    if (rc) return rc;
+    AttnWs w;
+    attn_carve(w, (char *)workspace, Nq, Nk, C, D, k > Nk ? Nk : k, queries_alias_keys != 0);
+    if (!workspace || workspace_bytes < w.total) return DDG_E_WORKSPACE;
+    k_sum_counts<<<1, 64, 0, (hipStream_t)stream>>>(w.L2.cnt, C, out_count_dev);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
 }
 
 extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset, const float *Xk0,

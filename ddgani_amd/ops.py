@@ -496,6 +496,21 @@ class AttnPlan:
         return (self.out, tau, nval) if debug else self.out
 
 
+def attn_set_key_chunk(positions: int):
+    """ddg_attn_set_key_chunk (tests / tuning): fixed key-chunk length of the screening path, 0 = default, -1 = environment"""
+    check(lib().ddg_attn_set_key_chunk(int(positions)), "ddg_attn_set_key_chunk")
+
+
+def attn_fallback_pairs(Nq: int, Nk: int, layout: FieldLayout, k: int, alias: bool, device) -> int:
+    """ddg_attn_fallback_pairs: pairs of the last fill on the cached attention workspace that took the exact fp32
+    fallback (synchronises)."""
+    ws = _ws_cache[(str(device), "attn")]
+    out = torch.zeros(1, dtype=torch.int32, device=device)
+    check(lib().ddg_attn_fallback_pairs(Nq, Nk, layout.C, layout.D, int(k), int(alias), out.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), _stream()), "ddg_attn_fallback_pairs")
+    return int(out.item())
+
+
 # ----------------------------------------------------------------------------- 8(f) row 1: Learner
 def learner_train(x_train, y_train, x_valid, y_valid, W, b, epochs: int, lr: float = 0.01):
     """``epochs`` full-batch SGD steps of the reference's Learner (model/Learner.py:43-67) on the device, then its

@@ -318,20 +318,29 @@ int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads
  * mq/mk: uint8 0/1 [rows,C].  W: [C,D].  offsets: int32[C+1] on the HOST here.
  * k >= 1.  k <= DDG_MAX_TOPK_REG selects AND fills in registers (one similarity pass; a two-way
  * tie at the k-th logit keeps both keys right there, pairs with a longer exact tie take a second
- * pass); larger k uses an exact 5-level radix select
- * on the logits (5 similarity passes + a fill pass).
+ * pass).  Larger k (the reference's top_k = 0.05 means k = 0.05 N) takes the WINDOW selection on
+ * tables of >= 16 384 keys: the k-th logit is bracketed on a strided sample of a column's keys (three
+ * cheap passes; the sample grows with the key count so that the bracket's bins stay listable), one
+ * full pass histograms the bracket (exact count above it, the bin of the k-th logit, its rank in the
+ * bin), one full pass accumulates everything above that bin and lists the bin's keys, and the k-th
+ * logit is selected exactly inside the list: two full passes on the f16 MFMA with both operands split
+ * in two halves (fp32-class products, |error| <= 3 * 2^-22 * sum |q||k|).  Smaller tables, pairs
+ * whose bracket missed and DDG_ATTN_RADIX=1 use the exact 5-level radix select on fp32 logits
+ * (5 similarity passes + a fill pass).
  * Optional debug outputs (NULL to skip): out_tau [Nq,C] (NaN where mq==1, -inf when all
  * valid keys are kept), out_nvalid int32 [Nq,C].
  * ------------------------------------------------------------------------------------- */
 /* mode: how the similarity of the register path (k <= DDG_MAX_TOPK_REG) is evaluated.
  *   DDG_ATTN_F32          fp32 MFMA (v_mfma_f32_32x32x2_f32) for every logit.
- *   DDG_ATTN_BF16_FILTER  bf16 MFMA (v_mfma_f32_32x32x16_bf16) screens every logit with a rigorous
- *                         error margin; every key that could reach the k+2 largest exact logits is
- *                         re-scored in fp32, and only fp32 values are ranked and weighted: the kept
- *                         sets and fills are those of fp32 arithmetic (up to fp32 summation order), at
- *                         the bf16 matrix rate.  Larger k (radix path) always runs in fp32. */
+ *   DDG_ATTN_F16_FILTER   (= DDG_ATTN_BF16_FILTER, the name of round 1, whose screen was bf16)
+ *                         16-bit MFMA (v_mfma_f32_32x32x16_f16 on power-of-two scaled operands) screens
+ *                         every logit with a rigorous error margin; every key that could reach the k+2
+ *                         largest exact logits is re-scored in fp32, and only fp32 values are ranked and
+ *                         weighted: the kept sets and fills are those of fp32 arithmetic (up to fp32
+ *                         summation order), at the 16-bit matrix rate.  Larger k ignores the mode. */
 #define DDG_ATTN_F32 0
 #define DDG_ATTN_BF16_FILTER 1
+#define DDG_ATTN_F16_FILTER DDG_ATTN_BF16_FILTER
 
 size_t ddg_attn_workspace_bytes(int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k);
 int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset,
@@ -349,9 +358,11 @@ int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset
  *            (k+2)-th is smaller, is filled right there (softmax over the kept k or k+1, gather
  *            of the key values: utils/util.py:484-496); pairs whose tie at the k-th logit may
  *            run past the list are flagged for the fill phase;
- *            larger k: exact 5-level radix select of tau (5 similarity passes)
+ *            larger k: window selection (three sample passes + one full histogram pass), or the exact
+ *            5-level radix select of tau (5 similarity passes) below 16 384 keys
  *   fill   : softmax over {s >= tau}, P^T X0, mask-merge (one more similarity pass) for the
- *            pairs select left open: the flagged ones, or all of them on the radix path
+ *            pairs select left open: the flagged ones, or all of them for larger k (window path:
+ *            the accumulate pass + in-list selection, then the radix path for flagged pairs)
  *                                                                      (utils/util.py:463-496)
  * k and mode must be the same in the three calls.
  * queries_alias_keys: 1 when prepare was called with identical query / key arrays. */
@@ -365,6 +376,17 @@ int ddg_attn_select(const float *Xq0, int64_t n_query_rows, int64_t n_key_rows, 
 int ddg_attn_fill(const int32_t *offsets_host, int64_t n_query_rows, int64_t n_key_rows, int C, int D,
                   int64_t k, int mode, int queries_alias_keys, float *out_code, float *out_tau,
                   int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream);
+/* Tuning / tests (no reference counterpart): key-chunk schedule of the screening path for all later calls of this
+ * process.  positions > 0: fixed chunks of that many key positions (rounded down to a multiple of 128, at least 128);
+ * 0: the default growing schedule; < 0: back to what DDG_FILT_CHUNK in the environment said at the first call.
+ * Results do not depend on the schedule (tests/test_gpu_parity.py holds two schedules against each other). */
+int ddg_attn_set_key_chunk(int64_t positions);
+/* Diagnostics (no reference counterpart): out_count_dev[0] <- the number of pairs that the last ddg_attn_fill on
+ * this workspace sent to its exact fp32 fallback -- window path: bracket missed or bin above the list capacity;
+ * register paths: ties longer than the list, candidate-slot overflow.  Undefined after the plain radix path. */
+int ddg_attn_fallback_pairs(int64_t n_query_rows, int64_t n_key_rows, int C, int D, int64_t k,
+                            int queries_alias_keys, int32_t *out_count_dev, void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * (f1) the "data-utility" Learner: train_L_code                 model/Learner.py:43-67

@@ -10,8 +10,3 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-
-# the library reads DDG_FILT_CHUNK once per process unless this is set before its first call: the attention parity tests
-# switch key-chunk schedules inside one process (tests/test_gpu_parity.py)
-import os
-os.environ.setdefault("DDG_FILT_CHUNK_RELOAD", "1")

@@ -362,15 +362,15 @@ def test_attn_full_size_modes_agree_and_match_fp64(dev):
     lo, hi = 300_000, 301_536
     Xq, mq = tab.X_attn[lo:hi].contiguous(), tab.m8[lo:hi].contiguous()
     outs, taus = [], []
-    for mode, chunk in ((1, None), (1, "40000"), (0, None)):
+    for mode, chunk in ((1, None), (1, 40000), (0, None)):
         if chunk:
-            os.environ["DDG_FILT_CHUNK"] = chunk
+            ops.attn_set_key_chunk(chunk)
         try:
             o, t, nv = ops.attn_topk_fill(Xq, mq, tab.X_attn, tab.m8, tab.W, tab.layout, tab.k, q_row_offset=lo,
                                           debug=True, mode=mode)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("DDG_FILT_CHUNK", None)
+            ops.attn_set_key_chunk(-1)
         outs.append(o)
         taus.append(t)
     for o, t in zip(outs[:2], taus[:2]):
@@ -590,6 +590,55 @@ def test_attn_window_path_equals_radix(dev, rows, k, cap, arith):
         bad = (cell > 1e-5) & fin
         assert int(bad.sum()) <= 0.02 * int(fin.sum()), (int(bad.sum()), int(fin.sum()))
         assert float(cell[fin].max()) < 2.0 / k + 1e-3      # a flipped near-tie moves one key of k in or out
+
+
+def _fp64_spot_pairs(tab, lo, mq_h, o, t, k, n_rows, per_row, seed):
+    """(row, column) pairs of a query shard against the fp64 closed form: the k-th logit within 1e-6, the fill within
+    1e-5 plus the weight of the keys whose logit lies within 1e-6 of it (near-ties: exempt by the north star)"""
+    X64, W64, m, off = tab.X_attn.double(), tab.W.double(), tab.m8, tab.layout.offsets
+    rng = np.random.default_rng(seed)
+    with_missing = np.where((mq_h == 0).any(1))[0]
+    checked = 0
+    for j in rng.choice(with_missing, n_rows, replace=False):
+        for c in np.where(mq_h[j] == 0)[0][:per_row]:
+            keys = torch.nonzero(m[:, c] == 1).flatten()
+            keys = keys[keys != lo + j]
+            s = (X64[keys] @ (W64[c] * X64[lo + j])).cpu().numpy()
+            kth = np.partition(s, len(s) - k)[len(s) - k]
+            xv = X64[keys][:, off[c]:off[c + 1]].cpu().numpy()
+            keep = s >= kth
+            w = np.exp(s - s.max())
+            Z = w[keep].sum()
+            ref = (w[keep] @ xv[keep]) / Z
+            band = np.abs(s - kth) <= 1e-6
+            slack = (w[band, None] * np.abs(xv[band] - ref)).sum(0) / Z + 1e-5
+            assert abs(float(t[j, c]) - kth) <= 1e-6, (j, c, float(t[j, c]), kth)
+            got = o[j, off[c]:off[c + 1]].double().cpu().numpy()
+            assert np.all(np.abs(got - ref) <= slack), (j, c, np.abs(got - ref).max(), slack.max())
+            checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("rows,frac", [(3_200_000, 0.05), (3_200_000, 0.2)])
+def test_attn_window_scales_past_two_million_keys(dev, rows, frac):
+    """The reference's top_k = 0.05 (and a larger fraction) on the c4 shape (128 numeric columns, MCAR 0.5) at
+    3.2M rows = 1.6M valid keys per column and k = 160 000 / 640 000: with round 2's fixed 8 192-key sample the selected
+    bin held ~ 5.5e-4 * nk keys and every pair past ~ 2M valid keys overflowed its 1 024-entry list into the six-pass radix
+    fallback; the sample now grows with nk^2 (win_kstride, csrc/attn.hip).  A 256-row query shard against all keys:
+    NO pair in the fallback, k-th logit and fills against the fp64 closed form."""
+    ops = _ops()
+    from ddgani_amd import synth
+    k = int(rows * frac)
+    tab = synth.make_table("c4", dev, rows=rows)
+    lo, hi = rows // 2, rows // 2 + 256
+    Xq, mq = tab.X_attn[lo:hi].contiguous(), tab.m8[lo:hi].contiguous()
+    o, t, nv = ops.attn_topk_fill(Xq, mq, tab.X_attn, tab.m8, tab.W, tab.layout, k, q_row_offset=lo, debug=True, mode=1)
+    torch.cuda.synchronize()
+    n_fallback = ops.attn_fallback_pairs(hi - lo, rows, tab.layout, k, False, dev)
+    fin = ~torch.isnan(t)
+    assert int(fin.sum()) > 10_000 and int(nv[fin].min()) > 1_500_000
+    assert n_fallback == 0, f"{n_fallback} of {int(fin.sum())} pairs took the radix fallback"
+    assert _fp64_spot_pairs(tab, lo, mq.cpu().numpy(), o, t, k, 3, 2, seed=5) >= 6
 
 
 def test_attn_large_k_c3_full_size(dev):
