@@ -330,6 +330,14 @@ def main():
         }
         if world == 1:
             res["roofline_other_kernels"] = other_rooflines(ops, P, xd, Md, lay, T, sched_host)
+            # SURVEY 8(d) "plus (separately) training steps/s": the B = 128 generator + discriminator steps on THIS table at
+            # its full row count, after the timed region (not part of `value`)
+            import bench_train
+            ep = 50
+            tdt = bench_train.measure(tab, dev, comm, ep)
+            res["training"] = {"metric": "training steps/s (generator + discriminator minibatch steps, B=128, Adam after each)",
+                               "value": ep * 2 * T / tdt, "unit": "steps/s", "ms_per_step": tdt / (ep * 2 * T) * 1e3,
+                               "rows": N, "steps": ep * 2 * T, "rng": "chip", "graph_replay": os.environ.get("DDG_TRAIN_GRAPH", "1") != "0"}
         if not a.no_cpu and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, lay.widths, k, T, lay.D, N, a.cpu_rows)
         else:

@@ -13,6 +13,46 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+def measure(tab, dev, comm, epochs, warm_epochs=3):
+    """seconds for `epochs` epochs of T generator + T discriminator minibatch steps (B = 128, Adam after each) on the
+    table `tab`, on-chip random numbers, the throughput-mode loop of model/Diffusion.py (graph replay on one rank)"""
+    from ddgani_amd import ops
+    from ddgani_amd.model import Diffusion as D_, Discriminator_model as DM
+    lay, T = tab.layout, tab.T
+
+    class F:
+        def __init__(s, w): s.w = w; s.data_type = "Categorical Data" if w > 1 else "Numerical Data"
+        def dim(s): return s.w
+    torch.manual_seed(3407)
+    G = D_.Generator_x0(lay.D, 2 * lay.D, lay.D, T + 1, [F(w) for w in lay.widths]).to(dev)
+    Dn = DM.Discriminator_noise_x(2 * lay.D, lay.D // 2, lay.C, T + 1).to(dev)
+    optG = D_._NetState(G.device_params(refresh=True), ops.GEN_KEYS, 1e-4, 1e-4)
+    optD = D_._NetState(Dn.device_params(refresh=True), ops.DISC_KEYS, 1e-4, 0.0)
+    DS = D_.Diffusion_setting(T, lay.D, dev)
+    m_data = tab.m8.float()
+    lw = {"Res_weight": 100, "G_D_weight": 1, "D_weight": 0.2, "L_weight": 0.1}
+    rnd = D_.ChipRandom(0)
+
+    def epoch(e):
+        D_.train_one_epoch_Generator(G, Dn, DS, tab.x_diff, optG, None, 0.0, e, epochs, T, dev, None, tab.M, m_data, lw,
+                                     [], None, None, rnd=rnd, comm=comm)
+        D_.train_one_epoch_discriminator_noise_x(G, Dn, DS, tab.x_diff, optD, None, 0.0, e, epochs, T, dev, None, tab.M,
+                                                 m_data, lw, rnd=rnd, comm=comm)
+    try:
+        for e in range(1, warm_epochs + 1):
+            epoch(e)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e in range(1, epochs + 1):
+            epoch(e)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    finally:
+        gs = getattr(rnd, "_graphs", None)
+        if gs is not None:
+            gs.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3")
@@ -41,39 +81,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
-    from ddgani_amd import ops, synth
+    from ddgani_amd import synth
     from ddgani_amd import dist as ddist
-    from ddgani_amd.model import Diffusion as D_, Discriminator_model as DM
     comm = ddist.Comm()
     tab = synth.make_table(a.workload, dev, rows=a.rows)
     lay, T = tab.layout, tab.T
-
-    class F:
-        def __init__(s, w): s.w = w; s.data_type = "Categorical Data" if w > 1 else "Numerical Data"
-        def dim(s): return s.w
-    torch.manual_seed(3407)
-    G = D_.Generator_x0(lay.D, 2 * lay.D, lay.D, T + 1, [F(w) for w in lay.widths]).to(dev)
-    Dn = DM.Discriminator_noise_x(2 * lay.D, lay.D // 2, lay.C, T + 1).to(dev)
-    optG = D_._NetState(G.device_params(refresh=True), ops.GEN_KEYS, 1e-4, 1e-4)
-    optD = D_._NetState(Dn.device_params(refresh=True), ops.DISC_KEYS, 1e-4, 0.0)
-    DS = D_.Diffusion_setting(T, lay.D, dev)
-    m_data = tab.m8.float()
-    lw = {"Res_weight": 100, "G_D_weight": 1, "D_weight": 0.2, "L_weight": 0.1}
-    rnd = D_.ChipRandom(0)
-
-    def epoch(e):
-        D_.train_one_epoch_Generator(G, Dn, DS, tab.x_diff, optG, None, 0.0, e, a.epochs, T, dev, None, tab.M, m_data, lw,
-                                     [], None, None, rnd=rnd, comm=comm)
-        D_.train_one_epoch_discriminator_noise_x(G, Dn, DS, tab.x_diff, optD, None, 0.0, e, a.epochs, T, dev, None, tab.M,
-                                                 m_data, lw, rnd=rnd, comm=comm)
-    for e in range(1, 4):
-        epoch(e)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for e in range(1, a.epochs + 1):
-        epoch(e)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt = measure(tab, dev, comm, a.epochs)
     steps = a.epochs * 2 * T
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")

@@ -420,12 +420,12 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     // one after the other; once the running sum passes ~ 1e5 its ulp is no longer small against the SPREAD of the addends
     // and round-to-nearest stops being unbiased: measured +3e-4 (k = 320 000) to +1e-3 (k = 640 000) relative error of the
     // weight sum Z, i.e. of every filled value, against 1e-7 for a pairwise fp32 sum (the reference's GEMM).  So the registers
-    // (and the LDS rows of wide column blocks) only hold the sums of FLUSH_TILES tiles; they are then added to a second level
+    // (and the LDS rows of wide column blocks) only hold the sums of FLUSH_TILES tiles (1 024 addends per lane: their ulp stays 400x below the spread); they are then added to a second level
     // -- out_code itself and zab / a register for Z -- whose addends vary by far more than its ulp.
     // Key lists below 65 536 entries keep ONE level (their sums stay far below the biased regime, and a changed summation
     // order would move the exactly tied categorical votes of small tables, whose arg-max the reference's rounding decides:
     // tests/test_gpu_e2e.py pins those).
-    constexpr int FLUSH_TILES = 8;
+    constexpr int FLUSH_TILES = 64;
     const bool two_level = nk >= 65536;
     float Z2 = 0.f;                                           // MODE_FILL: second level of Z
     if constexpr (MODE == MODE_WFILL || MODE == MODE_FILL) {
@@ -438,8 +438,14 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
     auto flush = [&](auto onec) {
         constexpr bool ONE = decltype(onec)::value;            // only accr[0] / acc1 is live
         if constexpr (MODE == MODE_WFILL || MODE == MODE_FILL) {
-            const bool on = h == 0 && ((MODE == MODE_WFILL) ? active : qrow >= 0);
-            float *dst = p.out_code + (int64_t)(qrow < 0 ? 0 : qrow) * p.D + off_c;
+            // opaque copies: nothing derived from them (addresses, predicates) can be hoisted out of the key loop, whose
+            // register budget has no room for it
+            int q_ = qrow, tid_ = tid;
+            uint32_t slo_ = (uint32_t)slot, shi_ = (uint32_t)((uint64_t)slot >> 32);
+            asm volatile("" : "+v"(q_), "+v"(tid_), "+v"(slo_), "+v"(shi_));
+            const int64_t slot_ = (int64_t)(((uint64_t)shi_ << 32) | slo_);
+            const bool on = (tid_ & 32) == 0 && ((MODE == MODE_WFILL) ? active : q_ >= 0);
+            float *dst = p.out_code + (int64_t)(q_ < 0 ? 0 : q_) * p.D + off_c;
             if (MODE == MODE_FILL ? d_c == 1 : d_c <= 8) {
 #pragma unroll
                 for (int e = 0; e < (ONE || MODE == MODE_FILL ? 1 : 8); ++e) {
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                     r = 0.f;
                 }
             } else {
-                float *accb = extra + (MODE == MODE_WFILL ? QPB + XOFF : 0) + (int64_t)tid * p.dcs;
+                float *accb = extra + (MODE == MODE_WFILL ? QPB + XOFF : 0) + (int64_t)tid_ * p.dcs;
                 __syncthreads();
                 if (on) {
                     const float *a1 = accb + (int64_t)32 * p.dcs;
@@ -460,7 +466,7 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             }
             if constexpr (MODE == MODE_WFILL) {
                 const float Zt = Z + __shfl_xor(Z, 32);
-                if (on) p.zab[slot] += Zt;
+                if (on) p.zab[slot_] += Zt;
             } else {
                 Z2 += Z;
             }
@@ -774,7 +780,11 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             int x_cur = 0, x_new = 512;             // side tile of tile t, of tile t+2 (floats past xs0)
             auto piped = [&](auto onec) {
                 constexpr bool ONE = decltype(onec)::value;      // MODE_WFILL: column blocks of one element
-                for (int t = 0; t + 1 < ntk; ++t) {
+                // (segments of FLUSH_TILES tiles, the second accumulation level between them: outside the inner loop, whose
+                // register budget it must not touch)
+                for (int tb = 0; tb + 1 < ntk; tb += FLUSH_TILES) {
+                const int te = min(tb + FLUSH_TILES, ntk - 1);
+                for (int t = tb; t < te; ++t) {
                     float *cur = (t & 1) ? kbuf1 : kbuf0;
                     float *nxt = (t & 1) ? kbuf0 : kbuf1;
                     // tile t+2 (rows and side values; past the end: copies of the last key), key-list indices of tile t+3
@@ -869,9 +879,6 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                             }
                         }
                     }
-                    if constexpr (MODE == MODE_WFILL) {
-                        if (two_level && (t & (FLUSH_TILES - 1)) == FLUSH_TILES - 1) flush(onec);
-                    }
                     side_commit(xs0 + x_new);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t+2 are in LDS
                     __syncthreads();
@@ -879,6 +886,10 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
                     for (int g = 0; g < 16; ++g) pa[g] = fmaf(nx[g], qinvx, na[g] * qinv);      // the logits of tile t+1
                     x_cur = x_cur == 512 ? 0 : x_cur + 256;
                     x_new = x_new == 512 ? 0 : x_new + 256;
+                }
+                if constexpr (MODE == MODE_WFILL) {
+                    if (two_level) flush(onec);
+                }
                 }
             };
             if (MODE == MODE_WFILL && d_c == 1) {
@@ -891,15 +902,18 @@ __global__ __launch_bounds__(256, (KS4 >= 32 ? 1 : 2)) void k_attn(AttnArgs p) {
             epi(pa, ntk - 1, ((ntk - 1) & 1) ? kbuf1 : kbuf0, xs0 + x_cur);
         }
     } else {
-        for (int t = 0; t < ntk; ++t) {
-            float *cur = (t & 1) ? kbuf1 : kbuf0;
-            float *nxt = (t & 1) ? kbuf0 : kbuf1;
-            if (t + 1 < ntk) prefetch(t + 1);
-            f32x16 acc = mma(cur);
-            epi(acc, t, cur, (t & 1) ? xs1 : xs0);
-            if (two_level && (t & (FLUSH_TILES - 1)) == FLUSH_TILES - 1) flush(std::false_type{});
-            if (t + 1 < ntk) commit(nxt, (t & 1) ? xs0 : xs1);
-            __syncthreads();
+        for (int tb = 0; tb < ntk; tb += FLUSH_TILES) {
+            const int te = min(tb + FLUSH_TILES, ntk);
+            for (int t = tb; t < te; ++t) {
+                float *cur = (t & 1) ? kbuf1 : kbuf0;
+                float *nxt = (t & 1) ? kbuf0 : kbuf1;
+                if (t + 1 < ntk) prefetch(t + 1);
+                f32x16 acc = mma(cur);
+                epi(acc, t, cur, (t & 1) ? xs1 : xs0);
+                if (t + 1 < ntk) commit(nxt, (t & 1) ? xs0 : xs1);
+                __syncthreads();
+            }
+            if (two_level) flush(std::false_type{});
         }
     }
 

@@ -140,9 +140,18 @@ def _encode_columns(miss_data, categorical_cols):
             _, enc = np.unique(arr.astype(np.str_), return_inverse=True)
             enc = enc + 1
         else:
-            enc = np.zeros_like(arr)
-            for i, b in enumerate(np.array_split(np.sort(arr), 10)):
-                enc[np.isin(arr, b)] = i
+            # chunk i of np.array_split(sorted, 10) that holds the value's LAST occurrence (the reference assigns
+            # enc[isin(arr, chunk_i)] = i for i = 0..9 in turn: O(N^2 / 10) there, two binary searches per value here)
+            v = arr.astype(np.float64)
+            srt = np.sort(v)
+            n = len(srt)
+            sizes = np.full(10, n // 10)
+            sizes[:n % 10] += 1
+            starts = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            last = np.searchsorted(srt, v, side="right") - 1
+            enc = np.searchsorted(starts, last, side="right") - 1
+            enc[np.isnan(v) | (last < 0)] = 0                       # NaN is in no chunk: stays 0 as in the reference
+            enc = enc.astype(object) if arr.dtype == object else enc.astype(arr.dtype)
         out.append(enc)
     return out
 

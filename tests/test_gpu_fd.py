@@ -89,3 +89,60 @@ def test_fd_eval_against_torch():
     ops.fd_train_epoch(P, X.to(dev), Y.to(torch.int32).to(dev), perm.to(dev), batch=256, lr=0.02)
     for got, ref in zip((P.W1, P.b1, P.W3, P.b3), W):
         assert (got.cpu() - ref.detach()).abs().max().item() < 2e-6
+
+
+def test_fd_plugin_at_200k_rows_mixed_table():
+    """--UseFD beyond the 1 000-row `hospital`: a 200 000-row mixed table (4 categorical + 2 numeric columns, MCAR 0.2)
+    with planted dependencies  A -> B (B = A mod 4),  A -> D (D = A div 4),  (B, D) -> A,  and an independent column C.
+    get_FD_model_Tree = the host discovery (np.unique groupings, model/FD_model.py:279-307 of the reference) + one
+    classifier per dependency trained on the GPU (ddg_fd_train_epoch): the discovered set is exactly the planted one,
+    every classifier reaches accuracy 1 on its observed rows (the early exit of train_Model), and get_my_FD_loss on a
+    batch equals a plain torch forward of the trained weights to 1e-5.
+    (BASELINE config 5's synthetic table is all-numeric, so --UseFD discovers nothing there: the plug-in only takes
+    categorical right-hand sides, model/FD_model.py:120-128 of the reference.)"""
+    import pandas as pd
+    from ddgani_amd.model import FD_model as F
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    N = 200_000
+    A = rng.integers(0, 12, N)
+    cols = [A, A % 4, rng.integers(0, 6, N), A // 4, rng.normal(size=N), rng.uniform(size=N)]
+    cards = [12, 4, 6, 3, 1, 1]
+    cat = [0, 1, 2, 3]
+    data_m = (rng.uniform(size=(N, 6)) < 0.8).astype(np.int64)
+    miss = pd.DataFrame({i: (np.where(data_m[:, i] == 1, cols[i].astype(str), "Null") if i in cat
+                             else np.where(data_m[:, i] == 1, cols[i], 0.0)) for i in range(6)})
+    # association order (what sort_corr would give): any order works for the planted set; use descending index distance
+    corr = np.abs(rng.uniform(size=(6, 6)))
+    sort_corr = {i: sorted(range(6), key=lambda j: corr[i][j], reverse=True) for i in range(6)}
+    fields = [_F(c) for c in cards]
+    code = np.zeros((N, sum(cards)), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(cards)])
+    for i in range(6):
+        if i in cat:
+            code[np.arange(N), off[i] + cols[i]] = 1.0
+        else:
+            code[:, off[i]] = cols[i]
+    M = np.repeat(data_m, cards, axis=1).astype(np.float32)
+    zero_feed = torch.tensor(code * M).to(dev)
+    torch.manual_seed(0)
+    models = F.get_FD_model_Tree(miss, data_m, cat, zero_feed, fields, dev, sort_corr)
+    found = sorted((sorted(m.x_index_list), m.y_index) for m in models)
+    assert found == [([0], 1), ([0], 3), ([1, 3], 0)], found
+    full = torch.tensor(code).to(dev)
+    for m in models:
+        rows = np.ones(N, dtype=bool)
+        for c in m.x_index_list + [m.y_index]:
+            rows &= data_m[:, c] == 1
+        X, Y = F._fd_input(full[torch.as_tensor(np.nonzero(rows)[0], device=dev)], fields, m.x_index_list, m.y_index)
+        assert F.test_model(X, Y.to(torch.int32), m) == 1.0, (m.x_index_list, m.y_index)
+    batch = full[:4096]
+    loss = float(F.get_my_FD_loss(models, batch, fields))
+    ref = 0.0
+    for m in models:
+        X, Y = F._fd_input(batch, fields, m.x_index_list, m.y_index)
+        sd = {k: v.to(dev).double() for k, v in m.state_dict().items()}
+        h = torch.relu(X.double() @ sd["fc1.weight"].T + sd["fc1.bias"])
+        logits = h @ sd["fc3.weight"].T + sd["fc3.bias"]
+        ref += float(torch.nn.functional.cross_entropy(logits, Y))
+    assert abs(loss - ref) <= 1e-5 * max(1.0, abs(ref)), (loss, ref)
