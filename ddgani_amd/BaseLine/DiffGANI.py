@@ -13,7 +13,7 @@ import torch
 from . import Mean
 from ..model import Diffusion, Discriminator_model
 from ..utils.get_attr_attn import get_attr_map_Null_kendall
-from ..utils.util import Data_convert, categorical_to_code, get_M_by_data_m, init_attn_2, sort_corr
+from ..utils.util import Data_convert, Data_convert_device, categorical_to_code, get_M_by_data_m, init_attn_2, sort_corr
 
 
 def get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, categorical_cols, continuous_cols, value_cat,
@@ -35,8 +35,12 @@ def get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, categor
     d_input_dim = attention_impute_data.shape[1]
     cat_to_code_data, enc = categorical_to_code(attention_impute_data.copy(), value_cat, enc)
     cat_to_code_data.columns = list(range(cat_to_code_data.shape[1]))
-    fields, feed_data = Data_convert(cat_to_code_data, param['model_name'], continuous_cols)
-    impute_data_code = torch.tensor(feed_data.values, dtype=torch.float).to(device)
+    if torch.device(device).type == "cuda":      # (f3) the encode on the device: no host one-hot table
+        fields, impute_data_code = Data_convert_device(cat_to_code_data, param['model_name'], continuous_cols, device)
+        feed_data = impute_data_code
+    else:
+        fields, feed_data = Data_convert(cat_to_code_data, param['model_name'], continuous_cols)
+        impute_data_code = torch.tensor(feed_data.values, dtype=torch.float).to(device)
     if args.UseFD == "True":
         # reference :30-39: dependencies are discovered on the table with missing cells, the classifiers are trained
         # on the observed part of the encoded table (M * code).  Their loss is a no_grad constant in the generator

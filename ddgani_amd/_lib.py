@@ -132,6 +132,10 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "ddg_score_table": (C.c_int, [c_f32p, c_f64p, c_u8p, c_i32p, c_u8p, c_f64p, c_f64p, c_u8p, c_f64p, c_f64p, c_f64p, c_f64p,
                                   C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "ddg_encode_table": (C.c_int, [c_f64p, c_i32p, c_u8p, c_u8p, c_f64p, c_f64p, c_f32p, C.c_int64, C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "ddg_decode_table": (C.c_int, [c_f32p, c_u8p, c_f64p, c_i32p, c_u8p, c_f64p, c_f64p, c_u8p, c_f64p, c_f64p, C.c_int64,
+                                   C.c_int, C.c_int, C.c_void_p]),
     "ddg_learner_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ddg_learner_train": (C.c_int, [c_f32p, c_i32p, C.c_int64, c_f32p, c_i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_float, c_f32p, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),

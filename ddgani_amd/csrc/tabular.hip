@@ -152,3 +152,106 @@ extern "C" int ddg_score_table(const float *code, const double *ori_norm, const 
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// (f3) encode of a table on the device: Data_convert                          utils/util.py:52-78
+//      NumericalField.convert  utils/field.py:65-67   K * (x - Min)   ("minmax")   /   (x - mu) / sigma   ("mean_std")
+//      CategoricalField.convert utils/field.py:138-150 one-hot over the sorted distinct values
+// vals [N][C] fp64: the numeric value, or for a categorical column the position of the cell's value among the column's
+// sorted distinct values (what CategoricalField.dict maps it to).  The arithmetic is the reference's: fp64 (pandas /
+// numpy on float64 columns), rounded ONCE to fp32 where the reference builds its tensor (torch.tensor(..., dtype=float),
+// BaseLine/DiffGANI.py:31): with the same K / Min / mu / sigma the result is bit-identical.  One thread per encoded
+// element (coalesced stores); HBM-bound: 4 N D bytes out, 8 N C in.  A categorical position outside its block leaves the
+// block all zero (the host mirror raises KeyError for such a value before it gets here).
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_encode_table(const double *__restrict__ vals, const int32_t *__restrict__ offsets,
+                                                      const uint8_t *__restrict__ is_cat, const uint8_t *__restrict__ mode,
+                                                      const double *__restrict__ pa, const double *__restrict__ pb,
+                                                      float *__restrict__ code, int64_t N, int C, int D) {
+    const int64_t total = N * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / D;
+        const int d = (int)(e - r * D);
+        int lo = 0, hi = C;                      // column of encoded position d: offsets[lo] <= d < offsets[lo + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offsets[mid] <= d) lo = mid; else hi = mid;
+        }
+        const double v = vals[r * C + lo];
+        float out;
+        if (is_cat[lo]) {
+            out = ((double)(d - offsets[lo]) == v) ? 1.f : 0.f;
+        } else if (mode[lo] == 0) {
+            out = (float)(pa[lo] * (v - pb[lo]));
+        } else {
+            out = (float)((v - pb[lo]) / pa[lo]);
+        }
+        code[e] = out;
+    }
+}
+#pragma clang fp contract(on)
+
+extern "C" int ddg_encode_table(const double *vals, const int32_t *offsets_dev, const uint8_t *is_cat_dev,
+                                const uint8_t *mode_dev, const double *scale_dev, const double *shift_dev, float *code,
+                                int64_t N, int C, int D, void *stream) {
+    if (!vals || !offsets_dev || !is_cat_dev || !mode_dev || !scale_dev || !shift_dev || !code || N < 0 || C < 1 || D < C)
+        return DDG_E_ARG;
+    if (N == 0) return DDG_OK;
+    int64_t g = ceil_div64(N * D, 256 * 4);
+    if (g > 256 * 16) g = 256 * 16;
+    k_encode_table<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(vals, offsets_dev, is_cat_dev, mode_dev, scale_dev, shift_dev,
+                                                                 code, N, C, D);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (f3) decode of a whole encoded table: reconvert_data                        utils/util.py:228-254
+// out[r,c] = obs[r,c] * m[r,c] + cur[r,c] * (1 - m[r,c])   (fp64, the reference's expression, :248), with cur the decoded
+// cell exactly as in k_score_table (numeric x / K + Min in numpy's arithmetic for the field, categorical: value of the
+// first arg-max position) and obs [N][C] fp64 the table the observed cells come from (categorical columns as their
+// ordinal codes).  The host maps the categorical codes back to labels (enc.inverse_transform).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decode_table(const float *__restrict__ code, const uint8_t *__restrict__ m,
+                                                      const double *__restrict__ obs, const int32_t *__restrict__ offsets,
+                                                      const uint8_t *__restrict__ is_cat, const double *__restrict__ dec_K,
+                                                      const double *__restrict__ dec_min, const uint8_t *__restrict__ dec_f32,
+                                                      const double *__restrict__ pos_value, double *__restrict__ out, int64_t N,
+                                                      int C, int D) {
+    const int64_t total = N * C;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = w / C;
+        const int c = (int)(w - r * C);
+        const int a = offsets[c], b = offsets[c + 1];
+        const float *x = code + r * D;
+        double v;
+        if (is_cat[c]) {
+            int best = a;
+            float bv = x[a];
+            for (int jx = a + 1; jx < b; ++jx)
+                if (x[jx] > bv) { bv = x[jx]; best = jx; }
+            v = pos_value[best];
+        } else {
+            if (dec_f32[c]) v = (double)__fadd_rn(__fdiv_rn(x[a], (float)dec_K[c]), (float)dec_min[c]);
+            else v = (double)x[a] / dec_K[c] + dec_min[c];
+        }
+        const double mm = m[w] ? 1.0 : 0.0;
+        out[w] = obs[w] * mm + v * (1.0 - mm);       // (this file is built with -ffp-contract=off: two products, one sum)
+    }
+}
+
+extern "C" int ddg_decode_table(const float *code, const uint8_t *m, const double *obs, const int32_t *offsets_dev,
+                                const uint8_t *is_cat_dev, const double *dec_K, const double *dec_min, const uint8_t *dec_f32,
+                                const double *pos_value, double *out, int64_t N, int C, int D, void *stream) {
+    if (!code || !m || !obs || !offsets_dev || !is_cat_dev || !dec_K || !dec_min || !dec_f32 || !pos_value || !out || N < 0 ||
+        C < 1 || D < C)
+        return DDG_E_ARG;
+    if (N == 0) return DDG_OK;
+    int64_t g = ceil_div64(N * C, 256 * 4);
+    if (g > 256 * 16) g = 256 * 16;
+    k_decode_table<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>(code, m, obs, offsets_dev, is_cat_dev, dec_K, dec_min, dec_f32,
+                                                                 pos_value, out, N, C, D);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

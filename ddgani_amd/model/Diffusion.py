@@ -578,8 +578,11 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
                 else:
                     L_loss = 0
                 if cur_r < r_M:
-                    impute_data = pd.DataFrame(reconvert_data(code, fields, value_cat, values, miss_data_x.copy(), data_m,
-                                                              enc))
+                    if scorer is not None:       # (f3) decode on the device, labels mapped back on the host
+                        impute_data = scorer.decode(code, miss_data_x.copy(), value_cat, values, enc)
+                    else:
+                        impute_data = pd.DataFrame(reconvert_data(code, fields, value_cat, values, miss_data_x.copy(),
+                                                                  data_m, enc))
                     impute_data.columns = values
                     b_e, r_M = epoch, cur_r
     finally:

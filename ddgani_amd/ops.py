@@ -573,6 +573,31 @@ def score_table(code, ori_norm, m8, layout: FieldLayout, dec_K, dec_min, dec_f32
     return sums
 
 
+def encode_table(vals, layout: FieldLayout, mode, scale, shift, out=None):
+    """ddg_encode_table: vals [N,C] fp64 (numeric value / categorical position) -> code [N,D] fp32.
+    mode uint8 [C] (0 = min-max, 1 = z-score), scale / shift fp64 [C]; all on the device."""
+    N = vals.shape[0]
+    off, cat = layout.on(vals.device)
+    if out is None:
+        out = torch.empty(N, layout.D, dtype=torch.float32, device=vals.device)
+    check(lib().ddg_encode_table(_ptr(vals, torch.float64), _ptr(off), _ptr(cat), _ptr(mode, torch.uint8),
+                                 _ptr(scale, torch.float64), _ptr(shift, torch.float64), _ptr(out, torch.float32), N,
+                                 layout.C, layout.D, _stream()), "ddg_encode_table")
+    return out
+
+
+def decode_table(code, m8, obs, layout: FieldLayout, dec_K, dec_min, dec_f32, pos_value):
+    """ddg_decode_table -> [N,C] fp64 on the device: observed cells of ``obs``, decoded cells elsewhere."""
+    N = code.shape[0]
+    off, cat = layout.on(code.device)
+    out = torch.empty(N, layout.C, dtype=torch.float64, device=code.device)
+    check(lib().ddg_decode_table(_ptr(code, torch.float32), _ptr(m8, torch.uint8), _ptr(obs, torch.float64), _ptr(off),
+                                 _ptr(cat), _ptr(dec_K, torch.float64), _ptr(dec_min, torch.float64),
+                                 _ptr(dec_f32, torch.uint8), _ptr(pos_value, torch.float64), _ptr(out), N, layout.C,
+                                 layout.D, _stream()), "ddg_decode_table")
+    return out
+
+
 # ----------------------------------------------------------------------------- 8(f) row 4: FD classifiers
 class FdParams:
     """Device tensors of an FDModel's used layers (fc1, fc3: model/FD_model.py:15-26), updated in place by

@@ -110,6 +110,41 @@ def field_widths(fields):
     return [int(f.dim()) for f in fields]
 
 
+def Data_convert_device(data, model_name, continuous_cols, device):
+    """``Data_convert`` (utils/util.py:52-78) with the encode itself on the GPU: the fields are learnt on the host
+    (min / max or mean / std of a numeric column, sorted distinct values of a categorical one: one pass each), the
+    [N, D] table is then written by ddg_encode_table from the [N, C] column values -- the one-hot blocks are never
+    materialised on the host (1M x 176 float64 = 1.4 GB for BASELINE config 3).
+    -> (fields, code [N, D] fp32 on ``device``), bit-identical to torch.tensor(Data_convert(...)[1].values, dtype=float)."""
+    from .. import ops
+    fields, cols, mode, scale, shift = [], [], [], [], []
+    cont = set(continuous_cols)
+    for i, _ in enumerate(list(data)):
+        col = np.asarray(data[i])
+        if i in cont:
+            f = NumericalField(model=model_name)
+            f.get_data(data[i])
+            f.learn()
+            cols.append(np.asarray(col, dtype=np.float64))
+            if model_name == "minmax":
+                mode.append(0); scale.append(float(f.K)); shift.append(float(f.Min))
+            else:
+                mode.append(1); scale.append(float(f.sigma)); shift.append(float(f.mu))
+        else:
+            f = CategoricalField("one-hot", noise=None)
+            f.get_data(data[i])
+            f.learn()
+            cols.append(f.codes(col.reshape(-1)).astype(np.float64))
+            mode.append(0); scale.append(1.0); shift.append(0.0)
+        fields.append(f)
+    dev = torch.device(device)
+    layout = ops.FieldLayout(field_widths(fields), dev)
+    vals = torch.from_numpy(np.ascontiguousarray(np.stack(cols, axis=1))).to(dev)
+    up = lambda v, dt: torch.tensor(np.asarray(v), dtype=dt).to(dev)
+    code = ops.encode_table(vals, layout, up(mode, torch.uint8), up(scale, torch.float64), up(shift, torch.float64))
+    return fields, code
+
+
 def get_M_by_data_m(data_m, filed, device):
     """reference: utils/util.py:369-383: the [N,C] mask with every column repeated over the encoded
     width of its field, as a float tensor on ``device``."""
@@ -196,6 +231,21 @@ class DeviceScorer:
         self.n_miss = (1.0 - m.astype(float)).sum(axis=0)
         self.is_num = is_num
 
+    def decode(self, code: torch.Tensor, miss_data_x, value_cat, values, enc):
+        """``reconvert_data`` (utils/util.py:228-254) of an encoded table on the device: one pass of ddg_decode_table
+        (observed cells of ``miss_data_x``, decoded cells elsewhere), then the categorical codes back to labels on
+        the host.  Like the reference it ordinal-encodes ``miss_data_x[value_cat]`` in place.  -> DataFrame [N, C]"""
+        from .. import ops
+        if value_cat:
+            miss_data_x[value_cat] = enc.transform(miss_data_x[value_cat])
+        obs = torch.from_numpy(np.ascontiguousarray(miss_data_x.values.astype(np.float64))).to(code.device)
+        out = ops.decode_table(code.contiguous(), self.m8, obs, self.layout, self.K, self.mn, self.f32, self.pos)
+        merged = pd.DataFrame(out.cpu().numpy())
+        if value_cat:
+            merged.columns = values
+            merged[value_cat] = enc.inverse_transform(merged[value_cat])
+        return merged
+
     def score(self, code: torch.Tensor):
         """-> (ARMSE, AMAE) of the encoded table ``code`` [N,D] (fp32, on the scorer's device)."""
         from .. import ops
@@ -226,10 +276,11 @@ def sort_corr(corr_map):
 
 
 # ------------------------------------------------------------------------------------------ attention fill
-def attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat):
+def attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat, device=None):
     """Host preparation of init_attn_2 (utils/util.py:390-448): mode-fill 'Null' categoricals,
     ordinal-encode, z-score / one-hot encode ("mean_std"), expand mask and column weights.
-    Returns (fields, X [N,D] fp32, M [N,D] fp32, W [C,D] fp32, offsets)."""
+    Returns (fields, X [N,D] fp32, M [N,D] fp32, W [C,D] fp32, offsets).  With a GPU ``device`` the encode runs there
+    (ddg_encode_table) and X, M, W are device tensors."""
     code = miss_data.copy()
     names = list(miss_data.columns)
     con_cols = [i for i in range(len(names)) if i not in categorical_cols]
@@ -241,6 +292,14 @@ def attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_c
                 break
     code, enc = categorical_to_code(code, value_cat, enc)
     code.columns = list(range(code.shape[1]))
+    if device is not None and torch.device(device).type == "cuda":
+        dev = torch.device(device)
+        fields, X = Data_convert_device(code, "mean_std", con_cols, dev)
+        widths = field_widths(fields)
+        wt = torch.tensor(widths, device=dev)
+        M = torch.repeat_interleave(torch.tensor(np.asarray(data_m), dtype=torch.float).to(dev), wt, dim=1)
+        W = torch.repeat_interleave(torch.tensor(np.asarray(corr_map), dtype=torch.float).to(dev), wt, dim=1)
+        return fields, X, M, W, widths
     fields, enc_code = Data_convert(code, "mean_std", con_cols)
     widths = field_widths(fields)
     X = torch.tensor(enc_code.values, dtype=torch.float)
@@ -279,11 +338,11 @@ def init_attn_2(corr_map, miss_data, data_m, categorical_cols, enc, value_cat, d
                                   "reference's unweighted branch (utils/util.py:467-476) are not built")
     from .. import ops
     values = miss_data.columns
-    fields, X, M, W, widths = attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat)
+    dev = torch.device(device)
+    fields, X, M, W, widths = attention_inputs(corr_map, miss_data, data_m, categorical_cols, enc, value_cat, device=dev)
     k = topk_count(X.shape[0], top_k)
     if k < 1:
         raise IndexError("init_attn_2: int(N * top_k) == 0 (the reference fails at values[-1] here)")
-    dev = torch.device(device)
     lay = ops.FieldLayout(widths, dev)
     X0 = (X * M).to(dev)
     m8 = torch.tensor(np.asarray(data_m) != 0, dtype=torch.uint8).to(dev)

@@ -465,6 +465,29 @@ int ddg_score_table(const float *code, const double *ori_norm, const uint8_t *m,
                     const double *pos_value, const double *norm_min, const double *norm_den, double *sums, int64_t N,
                     int C, int D, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * (f3) encode of a table: Data_convert                              utils/util.py:52-78
+ *      NumericalField.convert  utils/field.py:65-67   mode 0 ("minmax"):   scale * (x - shift)   scale = K, shift = Min
+ *                                                      mode 1 ("mean_std"): (x - shift) / scale   scale = sigma, shift = mu
+ *      CategoricalField.convert utils/field.py:138-150 one-hot over the sorted distinct values
+ * vals [N][C] fp64: numeric value, or the position of a categorical cell's value among its column's sorted distinct
+ * values.  fp64 arithmetic rounded once to fp32, as the reference's pandas columns -> torch.tensor(dtype=float):
+ * bit-identical to the host mirror for the same field constants.  code [N][D] fp32.  All arrays on the device.
+ * ------------------------------------------------------------------------------------- */
+int ddg_encode_table(const double *vals, const int32_t *offsets_dev, const uint8_t *is_cat_dev, const uint8_t *mode_dev,
+                     const double *scale_dev, const double *shift_dev, float *code, int64_t N, int C, int D,
+                     void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (f3) decode of a whole encoded table: reconvert_data             utils/util.py:228-254
+ * out[r,c] = obs[r,c] * m[r,c] + decoded[r,c] * (1 - m[r,c])  in fp64 (:248); decoded as in ddg_score_table (same
+ * dec_K / dec_min / dec_f32 / pos_value); obs [N][C] fp64: the table whose observed cells are kept, categorical
+ * columns as ordinal codes (the caller maps codes back to labels: enc.inverse_transform, :251-253).
+ * ------------------------------------------------------------------------------------- */
+int ddg_decode_table(const float *code, const uint8_t *m, const double *obs, const int32_t *offsets_dev,
+                     const uint8_t *is_cat_dev, const double *dec_K, const double *dec_min, const uint8_t *dec_f32,
+                     const double *pos_value, double *out, int64_t N, int C, int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

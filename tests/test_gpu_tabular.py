@@ -116,3 +116,48 @@ def test_device_score_on_reference_sampling_passes(tmp_path):
         armse, amae = scorer.score(torch.tensor(zp[f"p{i}__code"]).to(dev))
         rr, mm = zp[f"p{i}__scores"]
         assert abs(armse - rr) < 1e-12 and abs(amae - mm) < 1e-12, (armse, rr, amae, mm)
+
+
+def test_device_encode_and_decode_equal_the_host_mirror(prepared):
+    """(f3) ddg_encode_table == torch.tensor(Data_convert(...).values, dtype=float) bit for bit, in both encodings of the
+    path ("minmax": BaseLine/DiffGANI.py:27-29, "mean_std": utils/util.py:407), and against the reference's own encode
+    arrays (tests/golden/host_hospital.npz); ddg_decode_table + label mapping == reconvert_data (utils/util.py:228-254)
+    cell for cell, on encoded tables with exact ties inside one-hot blocks."""
+    from ddgani_amd.BaseLine import Mean
+    from ddgani_amd.utils import util
+    dev = torch.device("cuda:0")
+    z = load("host_hospital")
+    r, values, value_cat, enc = prepared["r"], prepared["values"], prepared["value_cat"], prepared["enc"]
+    data_m, con = r[2], r[6]
+    filled = Mean.fill_data_mean(r[7].copy(), con)
+    fdf = pd.DataFrame(filled, columns=values)
+    code, _ = util.categorical_to_code(fdf.copy(), value_cat, enc)
+    code.columns = list(range(code.shape[1]))
+    for model in ("minmax", "mean_std"):
+        fields_h, feed = util.Data_convert(code.copy(), model, con)
+        host = torch.tensor(feed.values, dtype=torch.float)
+        fields_d, devc = util.Data_convert_device(code.copy(), model, con, dev)
+        assert devc.dtype == torch.float32 and tuple(devc.shape) == tuple(host.shape)
+        assert torch.equal(devc.cpu(), host), float((devc.cpu() - host).abs().max())
+        assert [f.dim() for f in fields_d] == [f.dim() for f in fields_h]
+    for key in ("encode_minmax", "feed_minmax", "x_minmax"):          # the reference's own array, when the fixture holds it
+        if key in z.files:
+            _, devc = util.Data_convert_device(code.copy(), "minmax", con, dev)
+            assert np.array_equal(devc.cpu().numpy(), z[key].astype(np.float32))
+            break
+    fields, _ = util.Data_convert(code.copy(), "minmax", con)
+    scorer = util.DeviceScorer(fields, value_cat, values, r[0], data_m, enc, con, dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.tensor(z["decode_in"])
+    for i in range(3):
+        xr = x if i == 0 else torch.rand(x.shape, generator=g)
+        if i == 2:
+            xr[::5] = torch.round(xr[::5] * 4) / 4                      # exact ties: first maximum wins, as np.argmax
+        host = util.reconvert_data(xr, fields, value_cat, values, fdf.copy(), data_m, enc)
+        got = scorer.decode(xr.to(dev), fdf.copy(), value_cat, values, enc)
+        assert list(got.columns) == list(host.columns)
+        for c in host.columns:
+            if c in value_cat:
+                assert (got[c].values == host[c].values).all(), c
+            else:
+                assert np.array_equal(got[c].values.astype(float), host[c].values.astype(float)), c
