@@ -52,6 +52,11 @@ class FdWeights(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W3", "b3")]
 
 
+class DplainWeights(C.Structure):
+    """struct ddg_dplain_weights (include/ddgani.h)."""
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32)] + [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)   # ddg_allreduce_fn
 
 
@@ -136,6 +141,11 @@ SIGNATURES = {
                                    C.c_void_p]),
     "ddg_decode_table": (C.c_int, [c_f32p, c_u8p, c_f64p, c_i32p, c_u8p, c_f64p, c_f64p, c_u8p, c_f64p, c_f64p, C.c_int64,
                                    C.c_int, C.c_int, C.c_void_p]),
+    "ddg_dplain_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "ddg_dplain_grads": (C.c_int, [C.POINTER(DplainWeights), c_f32p, c_f32p, c_u8p, c_u8p, C.c_float, C.c_uint64, C.c_uint64,
+                                   C.c_int64, C.POINTER(DplainWeights), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ddg_dplain_fwd": (C.c_int, [C.POINTER(DplainWeights), c_f32p, c_u8p, c_u8p, C.c_float, C.c_uint64, C.c_uint64, C.c_int64,
+                                 c_f32p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ddg_learner_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ddg_learner_train": (C.c_int, [c_f32p, c_i32p, C.c_int64, c_f32p, c_i32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_float, c_f32p, c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -961,3 +961,205 @@ extern "C" int ddg_fd_eval(const ddg_fd_weights *w, const float *X, const int32_
 
 // this translation unit's copy of the stream-offset pointer (ddg_set_stream_offset, elementwise.hip)
 int ddg_tu_set_stream_off_train(const uint64_t *dev_ptr) { return set_stream_off_tu(dev_ptr); }
+
+// ---------------------------------------------------------------------------------------------
+// (f1, rest) the plain discriminator D that get_valid_data_index trains when fewer than 20 % of the rows are complete
+//                                                                    utils/util.py:623-646, model/Discriminator_model.py:5-39
+//   p = sigmoid(fc3(drop(relu(fc2(drop(relu(fc1(x))))))))     train mode: Dropout(0.2) live, also in the final scoring pass
+//   loss = -mean(m log(p + 1e-8) + (1 - m) log(1 - p + 1e-8))  over all N x C cells, 1 000 FULL-BATCH Adam steps (lr 0.002)
+// Full batch means N rows per step (10M at BASELINE config 4, where no row is complete): the three forward layers go
+// through ddg_linear (the wide f16-split kernel from 8 192 rows on), the input gradients likewise on transposed weights,
+// and the weight gradients dW = dZ^T H -- a reduction over ALL rows -- through k_gemm_tn below: row chunks x 32 x 32
+// output tiles on the fp32 MFMA, partial tiles reduced in a fixed order (deterministic).  The bias gradient is the extra
+// column of dZ^T [H | 1].  Dropout keeps come from explicit masks (parity: the caller draws them from torch's CPU generator
+// in the reference's order) or from Philox on chip.
+// ---------------------------------------------------------------------------------------------
+#define TN_ROWS 4096        // rows per workgroup of k_gemm_tn (1 024 per wave)
+// part[chunk][o][i] = sum_{r in chunk} dZ[r][o] * Hx[r][i],  Hx = [H | 1]  (i == in: the ones column)
+__global__ __launch_bounds__(256) void k_gemm_tn(const float *__restrict__ dZ, int out, const float *__restrict__ H, int in,
+                                                 int64_t rows, float *__restrict__ part) {
+    __shared__ float red[4][32 * 33];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
+    const int ti = blockIdx.x, to = blockIdx.y;
+    const int64_t chunk = blockIdx.z;
+    const int o = to * 32 + r32, i = ti * 32 + r32;
+    const bool ook = o < out, iok = i <= in;
+    const int64_t r0 = chunk * TN_ROWS + (int64_t)wid * (TN_ROWS / 4);
+    int64_t r1 = r0 + TN_ROWS / 4;
+    if (r1 > rows) r1 = rows;
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    for (int64_t r = r0; r < r1; r += 16) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t rr = r + 2 * u + h;
+            const bool rok = rr < r1;
+            a[u] = (rok && ook) ? dZ[rr * out + o] : 0.f;
+            b[u] = (rok && iok) ? (i == in ? 1.f : H[rr * in + i]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) red[wid][((g & 3) + 8 * (g >> 2) + 4 * h) * 33 + r32] = acc[g];
+    __syncthreads();
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    float *dst = part + chunk * (int64_t)out * (in + 1);
+    if (ti * 32 + c <= in) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rl = rg * 4 + k;
+            if (to * 32 + rl < out)
+                dst[(int64_t)(to * 32 + rl) * (in + 1) + ti * 32 + c] =
+                    (red[0][rl * 33 + c] + red[1][rl * 33 + c]) + (red[2][rl * 33 + c] + red[3][rl * 33 + c]);
+        }
+    }
+}
+// dW[o][i] (i < in) and db[o] (i == in) = sum over the chunks, ascending
+__global__ void k_tn_reduce(const float *__restrict__ part, int64_t nchunks, int out, int in, float *__restrict__ dW,
+                            float *__restrict__ db) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= out * (in + 1)) return;
+    float s = 0.f;
+    for (int64_t c = 0; c < nchunks; ++c) s += part[c * (int64_t)out * (in + 1) + e];
+    const int o = e / (in + 1), i = e - o * (in + 1);
+    if (i == in) db[o] = s; else dW[(int64_t)o * in + i] = s;
+}
+__global__ void k_transpose(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * cols) return;
+    const int r = e / cols, c = e - r * cols;
+    Wt[(int64_t)c * rows + r] = W[e];
+}
+// h = relu(z) * keep / (1 - p), in place
+__global__ void k_relu_drop_fwd(float *__restrict__ z, const uint8_t *__restrict__ drop, float drop_p, uint64_t seed,
+                                uint64_t stream_id, int64_t n) {
+    const float ks = 1.f / (1.f - drop_p);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float v = fmaxf(z[e], 0.f);
+        if (drop) v = drop[e] ? v * ks : 0.f;
+        else if (drop_p > 0.f) v = (philox_uniform4(seed, stream_id, (uint64_t)e >> 2)[e & 3] > drop_p) ? v * ks : 0.f;
+        z[e] = v;
+    }
+}
+// dz = dh * (h > 0 ? 1 / (1 - p) : 0): a kept unit with z > 0 has h = z / (1 - p) > 0, every other unit has h == 0
+__global__ void k_relu_drop_bwd(const float *__restrict__ dh, const float *__restrict__ hact, float drop_p,
+                                float *__restrict__ dz, int64_t n) {
+    const float ks = 1.f / (1.f - drop_p);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        dz[e] = hact[e] > 0.f ? dh[e] * ks : 0.f;
+}
+// z3 -> d(loss)/d(z3) in place (p = sigmoid(z3); torch's backward of the expression at utils/util.py:636), or p itself
+__global__ void k_dplain_out(float *__restrict__ z3, const float *__restrict__ m, int64_t n, int want_grad) {
+    const float inv = 1.f / (float)n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float p = 1.f / (1.f + expf(-z3[e]));
+        if (!want_grad) { z3[e] = p; continue; }
+        const float mm = m[e];
+        const float dp = -(mm / (p + 1e-8f) - (1.f - mm) / (1.f - p + 1e-8f)) * inv;
+        z3[e] = dp * p * (1.f - p);
+    }
+}
+
+struct DplainWs {
+    float *h1, *h2, *z3, *dh, *dz, *W2t, *W3t, *zero, *part;
+    int64_t nchunks;
+    size_t total;
+};
+static void dplain_carve(DplainWs &w, char *base, int64_t N, int D, int C) {
+    size_t o = 0;
+    auto f = [&](size_t n) { char *p = base ? base + o : nullptr; o += tal(n * 4); return (float *)p; };
+    w.h1 = f((size_t)N * D); w.h2 = f((size_t)N * D); w.z3 = f((size_t)N * C);
+    w.dh = f((size_t)N * D); w.dz = f((size_t)N * D);
+    w.W2t = f((size_t)D * D); w.W3t = f((size_t)D * C); w.zero = f((size_t)D);
+    w.nchunks = ceil_div64(N, TN_ROWS);
+    w.part = f((size_t)w.nchunks * D * (D + 1));
+    w.total = o;
+}
+extern "C" size_t ddg_dplain_workspace_bytes(int64_t rows, int in_dim, int out_dim) {
+    if (rows < 1 || in_dim < 1 || out_dim < 1 || out_dim > in_dim) return 0;
+    DplainWs w;
+    dplain_carve(w, nullptr, rows, in_dim, out_dim);
+    return w.total;
+}
+static inline unsigned gstride(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g > 65536 ? 65536 : (g < 1 ? 1 : g)); }
+
+static int dplain_forward(const ddg_dplain_weights *w, const float *x, const uint8_t *drop1, const uint8_t *drop2,
+                          float drop_p, uint64_t seed, uint64_t stream_id, int64_t N, DplainWs &ws, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int D = w->in_dim, C = w->out_dim;
+    int rc = ddg_linear(x, nullptr, D, w->W1, w->b1, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0,
+                        ws.h1, nullptr, N, D, D, stream);
+    if (rc) return rc;
+    k_relu_drop_fwd<<<gstride(N * D), 256, 0, s>>>(ws.h1, drop1, drop_p, seed, stream_id * 2, N * D);
+    rc = ddg_linear(ws.h1, nullptr, D, w->W2, w->b2, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0,
+                    ws.h2, nullptr, N, D, D, stream);
+    if (rc) return rc;
+    k_relu_drop_fwd<<<gstride(N * D), 256, 0, s>>>(ws.h2, drop2, drop_p, seed, stream_id * 2 + 1, N * D);
+    rc = ddg_linear(ws.h2, nullptr, D, w->W3, w->b3, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0,
+                    ws.z3, nullptr, N, D, C, stream);
+    if (rc) return rc;
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+static int gemm_tn(const float *dZ, int out, const float *H, int in, int64_t N, DplainWs &ws, float *dW, float *db, hipStream_t s) {
+    dim3 grid((unsigned)((in + 1 + 31) / 32), (unsigned)((out + 31) / 32), (unsigned)ws.nchunks);
+    k_gemm_tn<<<grid, 256, 0, s>>>(dZ, out, H, in, N, ws.part);
+    k_tn_reduce<<<(unsigned)((out * (in + 1) + 255) / 256), 256, 0, s>>>(ws.part, ws.nchunks, out, in, dW, db);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// one step up to the gradients (zero_grad + forward + loss.backward of utils/util.py:633-637)
+extern "C" int ddg_dplain_grads(const ddg_dplain_weights *w, const float *x, const float *m, const uint8_t *drop1,
+                                const uint8_t *drop2, float drop_p, uint64_t seed, uint64_t stream_id, int64_t rows,
+                                const ddg_dplain_weights *grads, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!w || !x || !m || !grads || rows < 1 || w->in_dim < 1 || w->out_dim < 1 || w->out_dim > w->in_dim) return DDG_E_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f || (ceil_div64(rows, TN_ROWS) > 65535)) return DDG_E_ARG;
+    const int D = w->in_dim, C = w->out_dim;
+    DplainWs ws;
+    dplain_carve(ws, (char *)workspace, rows, D, C);
+    if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = dplain_forward(w, x, drop1, drop2, drop_p, seed, stream_id, rows, ws, stream);
+    if (rc) return rc;
+    k_dplain_out<<<gstride(rows * C), 256, 0, s>>>(ws.z3, m, rows * C, 1);                       // z3 <- dz3
+    if ((rc = gemm_tn(ws.z3, C, ws.h2, D, rows, ws, grads->W3, grads->b3, s))) return rc;
+    k_transpose<<<g256((int64_t)C * D), 256, 0, s>>>(w->W3, C, D, ws.W3t);                       // W3 [C][D] -> [D][C]
+    // dh2 = dz3 W3: a layer with weight W3^T and a zero bias
+    if ((rc = zero_async(ws.zero, tal((size_t)D * 4), s))) return rc;
+    rc = ddg_linear(ws.z3, nullptr, C, ws.W3t, ws.zero, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0,
+                    ws.dh, nullptr, rows, C, D, stream);
+    if (rc) return rc;
+    k_relu_drop_bwd<<<gstride(rows * D), 256, 0, s>>>(ws.dh, ws.h2, drop_p, ws.dz, rows * D);
+    k_transpose<<<g256((int64_t)D * D), 256, 0, s>>>(w->W2, D, D, ws.W2t);
+    rc = ddg_linear(ws.dz, nullptr, D, ws.W2t, ws.zero, DDG_PRO_NONE, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0.f, 0, 0,
+                    ws.dh, nullptr, rows, D, D, stream);                                          // dh1 = dz2 W2
+    if (rc) return rc;
+    if ((rc = gemm_tn(ws.dz, D, ws.h1, D, rows, ws, grads->W2, grads->b2, s))) return rc;       // dW2 = dz2^T h1
+    k_relu_drop_bwd<<<gstride(rows * D), 256, 0, s>>>(ws.dh, ws.h1, drop_p, ws.dz, rows * D);    // dz1
+    if ((rc = gemm_tn(ws.dz, D, x, D, rows, ws, grads->W1, grads->b1, s))) return rc;           // dW1 = dz1^T x
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+// the scoring pass (utils/util.py:638: D_pro = curr_dis(impute_data_code), still in train mode): p_out [rows][out_dim]
+extern "C" int ddg_dplain_fwd(const ddg_dplain_weights *w, const float *x, const uint8_t *drop1, const uint8_t *drop2,
+                              float drop_p, uint64_t seed, uint64_t stream_id, int64_t rows, float *p_out, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!w || !x || !p_out || rows < 1 || w->in_dim < 1 || w->out_dim < 1 || w->out_dim > w->in_dim) return DDG_E_ARG;
+    if (drop_p < 0.f || drop_p >= 1.f) return DDG_E_ARG;
+    DplainWs ws;
+    dplain_carve(ws, (char *)workspace, rows, w->in_dim, w->out_dim);
+    if (!workspace || workspace_bytes < ws.total) return DDG_E_WORKSPACE;
+    int rc = dplain_forward(w, x, drop1, drop2, drop_p, seed, stream_id, rows, ws, stream);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    k_dplain_out<<<gstride(rows * w->out_dim), 256, 0, s>>>(ws.z3, nullptr, rows * w->out_dim, 0);
+    if ((rc = copy_f32_async(p_out, ws.z3, (size_t)rows * w->out_dim, s))) return rc;
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

@@ -520,10 +520,9 @@ def train_diffusion_discriminator(discriminator, generator_x, discriminator_nois
     M_tensor = get_M_by_data_m(data_m, fields, dev)
     x = impute_data_code.to(dev).contiguous()
     zero_feed_data = M_tensor * x
-    # validation split of the Learner; with rng="host" it runs where the reference's CPU run does, so
-    # that its dropout draws come from the same torch CPU stream (utils/util.py:623-646)
-    vdev = torch.device("cpu") if rng == "host" else dev
-    valid_data_index = get_valid_data_index(data_m, discriminator.to(vdev), impute_data_code.to(vdev), vdev)
+    # validation split of the Learner (utils/util.py:623-646); its fallback discriminator trains on the device, with the
+    # dropout keeps of the reference's CPU stream in parity mode
+    valid_data_index = get_valid_data_index(data_m, discriminator, impute_data_code, dev, rng=rng, seed=3047)
     vset = set(int(i) for i in valid_data_index)
     train_data_index = [i for i in range(len(data_m)) if i not in vset]
     label_data_code = torch.FloatTensor(label_data.values).to(dev)

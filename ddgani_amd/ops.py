@@ -534,6 +534,42 @@ def learner_train(x_train, y_train, x_valid, y_valid, W, b, epochs: int, lr: flo
     return out_loss[0], int(out_hit.item()) / xv.shape[0]
 
 
+DPLAIN_KEYS = ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias")
+
+
+class DplainParams:
+    """Device tensors of the plain discriminator ``D`` (model/Discriminator_model.py:5-39: fc1, fc2, fc3), shaped for
+    ParamGrads / ddg_adam_step like GenParams."""
+
+    def __init__(self, sd, device):
+        self.t = {k: sd[k].detach().to(device=device, dtype=torch.float32).contiguous() for k in DPLAIN_KEYS}
+        self.in_dim, self.out_dim = self.t["fc1.weight"].shape[1], self.t["fc3.weight"].shape[0]
+        self.c = _lib.DplainWeights(self.in_dim, self.out_dim, *[self.t[k].data_ptr() for k in DPLAIN_KEYS])
+
+
+def dplain_grads(P: DplainParams, grads: ParamGrads, x, m, drops=None, drop_p: float = 0.2, seed: int = 0,
+                 stream_id: int = 0):
+    """ddg_dplain_grads: one full-batch step of get_valid_data_index's discriminator up to the gradients."""
+    rows = x.shape[0]
+    ws = _workspace(lib().ddg_dplain_workspace_bytes(rows, P.in_dim, P.out_dim), x.device, "dplain")
+    g = _lib.DplainWeights(P.in_dim, P.out_dim, *[grads.g[k].data_ptr() for k in DPLAIN_KEYS])
+    d = [None, None] if drops is None else [_ptr(q, torch.uint8) for q in drops]
+    check(lib().ddg_dplain_grads(C.byref(P.c), _ptr(x, torch.float32), _ptr(m, torch.float32), d[0], d[1], float(drop_p),
+                                 int(seed), int(stream_id), rows, C.byref(g), ws.data_ptr(), ws.numel(), _stream()),
+          "ddg_dplain_grads")
+
+
+def dplain_fwd(P: DplainParams, x, drops=None, drop_p: float = 0.2, seed: int = 0, stream_id: int = 0):
+    """ddg_dplain_fwd -> p [rows, out_dim] (train-mode forward: dropout live)."""
+    rows = x.shape[0]
+    ws = _workspace(lib().ddg_dplain_workspace_bytes(rows, P.in_dim, P.out_dim), x.device, "dplain")
+    out = torch.empty(rows, P.out_dim, dtype=torch.float32, device=x.device)
+    d = [None, None] if drops is None else [_ptr(q, torch.uint8) for q in drops]
+    check(lib().ddg_dplain_fwd(C.byref(P.c), _ptr(x, torch.float32), d[0], d[1], float(drop_p), int(seed), int(stream_id),
+                               rows, _ptr(out), ws.data_ptr(), ws.numel(), _stream()), "ddg_dplain_fwd")
+    return out
+
+
 # ----------------------------------------------------------------------------- 8(f) row 2: column-association tables
 CODE_MISSING = 65535      # DDG_CODE_MISSING
 

@@ -359,10 +359,15 @@ def sample_x(x, batch_size):
     return x[rows, :], rows
 
 
-def get_valid_data_index(data_m, discriminator, impute_data_code, device):
+def get_valid_data_index(data_m, discriminator, impute_data_code, device, rng="host", seed=0):
     """reference: utils/util.py:623-646.  20 % of the rows for the Learner's validation split:
     sampled (python ``random``) from the complete rows when there are enough of them, otherwise the
-    complete rows plus the rows a freshly trained plain discriminator ``D`` scores lowest."""
+    complete rows plus the rows a freshly trained plain discriminator ``D`` scores lowest.
+    On a GPU ``device`` the 1 000 full-batch Adam steps of that discriminator run in the HIP library
+    (ddg_dplain_grads / ddg_adam_step / ddg_dplain_fwd).  rng="host": its dropout keeps are drawn from torch's CPU
+    generator exactly as the reference's CPU run draws them (two ``bernoulli_(0.8)`` of [N, input_dim] per pass, 1 001
+    passes), so a run seeded like the reference follows the reference's random stream; rng="chip": Philox on the
+    device (``seed``).  A CPU ``device`` keeps stock torch (the oracle-side path of the CPU tests)."""
     data_m = np.asarray(data_m)
     n = data_m.shape[0]
     valid = np.nonzero(np.all(data_m == 1, axis=1))[0].tolist()
@@ -370,19 +375,38 @@ def get_valid_data_index(data_m, discriminator, impute_data_code, device):
     if len(valid) >= want:
         return random.sample(valid, want)
     from ..model.Discriminator_model import D
-    from torch import optim
-    cur = D(discriminator.input_dim, discriminator.latent_dim, discriminator.out_dim).to(device)
-    opt = optim.Adam(cur.parameters(), lr=0.002)
-    cur.train()
-    m = torch.tensor(data_m).float().to(device)
-    x = impute_data_code.to(device)
-    for _ in range(1000):
-        opt.zero_grad()
+    cur = D(discriminator.input_dim, discriminator.latent_dim, discriminator.out_dim)      # (CPU: the reference's init draws)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        from torch import optim
+        cur = cur.to(dev)
+        opt = optim.Adam(cur.parameters(), lr=0.002)
+        cur.train()
+        m = torch.tensor(data_m).float().to(dev)
+        x = impute_data_code.to(dev)
+        for _ in range(1000):
+            opt.zero_grad()
+            p = cur(x)
+            loss = -torch.mean(m * torch.log(p + 1e-8) + (1 - m) * torch.log(1 - p + 1e-8))
+            loss.backward()
+            opt.step()
         p = cur(x)
-        loss = -torch.mean(m * torch.log(p + 1e-8) + (1 - m) * torch.log(1 - p + 1e-8))
-        loss.backward()
-        opt.step()
-    p = cur(x)
+    else:
+        from .. import ops
+        P = ops.DplainParams(cur.state_dict(), dev)
+        buf = ops.ParamGrads(P, ops.DPLAIN_KEYS, n_extra=0)
+        m = torch.tensor(data_m).float().to(dev).contiguous()
+        x = impute_data_code.to(dev).float().contiguous()
+        width = P.in_dim
+
+        def keeps():
+            if rng != "host":
+                return None
+            return [torch.empty(n, width).bernoulli_(0.8).to(torch.uint8).to(dev) for _ in range(2)]
+        for step in range(1000):
+            ops.dplain_grads(P, buf, x, m, drops=keeps(), seed=seed, stream_id=step + 1)
+            buf.adam_step(lr=0.002, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        p = ops.dplain_fwd(P, x, drops=keeps(), seed=seed, stream_id=1001)
     _, order = torch.sort(p.sum(dim=1))
     return np.union1d(valid, order[:want].cpu().numpy())
 

@@ -430,6 +430,29 @@ int ddg_fd_eval(const ddg_fd_weights *w, const float *X, const int32_t *Y, int64
                 float *out_ce_mean, void *workspace, size_t workspace_bytes, int64_t workspace_rows, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * (f1, rest) the plain discriminator D trained inside get_valid_data_index      utils/util.py:623-646
+ *                                                                               model/Discriminator_model.py:5-39
+ * p = sigmoid(fc3(drop(relu(fc2(drop(relu(fc1(x))))))))  with fc1, fc2: [in][in], fc3: [out][in]; Dropout(0.2) is live in
+ * every pass (the module stays in train mode, also when it scores the rows, :638).
+ * ddg_dplain_grads = zero_grad + forward + backward of  -mean(m log(p + 1e-8) + (1 - m) log(1 - p + 1e-8))  (:633-637)
+ * over ALL `rows` rows (full batch): the gradients of the six tensors go to `grads` (same struct, gradient buffers); the
+ * caller applies torch.optim.Adam(lr 0.002) with ddg_adam_step.  ddg_dplain_fwd = the scoring pass: p_out [rows][out].
+ * drop1 / drop2: uint8 keep masks [rows][in] (the caller's draws, e.g. torch's CPU generator in the reference's order) or
+ * NULL: Philox on chip (seed, stream_id * 2 + layer).  x [rows][in], m [rows][out] fp32.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ddg_dplain_weights {
+    int32_t in_dim, out_dim;
+    float *W1, *b1, *W2, *b2, *W3, *b3;
+} ddg_dplain_weights;
+size_t ddg_dplain_workspace_bytes(int64_t rows, int in_dim, int out_dim);
+int ddg_dplain_grads(const ddg_dplain_weights *w, const float *x, const float *m, const uint8_t *drop1,
+                     const uint8_t *drop2, float drop_p, uint64_t seed, uint64_t stream_id, int64_t rows,
+                     const ddg_dplain_weights *grads, void *workspace, size_t workspace_bytes, void *stream);
+int ddg_dplain_fwd(const ddg_dplain_weights *w, const float *x, const uint8_t *drop1, const uint8_t *drop2, float drop_p,
+                   uint64_t seed, uint64_t stream_id, int64_t rows, float *p_out, void *workspace, size_t workspace_bytes,
+                   void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * (f2) column-association map: the C^2 crosstabs of get_attr_map_Null_kendall
  *                                                   utils/get_attr_attn.py:61-77 (pd.crosstab per column pair)
  *

@@ -57,6 +57,14 @@ def _run_pipeline(tmp_path, tag, csv_name, rng="host", epochs=None):
     pins = {}
 
     def hook(epoch, G, Dn, vidx):
+        if epoch == 1 and "valid_index" in z.files:
+            # get_valid_data_index: hospital has fewer than 20 % complete rows, so the fallback discriminator is trained
+            # (1 000 full-batch Adam steps in the HIP library, dropout keeps from the reference's CPU stream) and the 160
+            # rows it scores lowest join the split (utils/util.py:623-646).  The selection is not reproducible to the row
+            # even by torch itself: the same CPU op sequence with 1 / 2 / 8 intra-op threads selects sets that differ in
+            # 11 - 13 entries (tools/valid_index_sensitivity.py; rows near the cut-off swap).  Bound: 40 entries
+            # (20 of 270 rows); measured 28.
+            pins["valid_rows_differing"] = int(len(np.setxor1d(np.asarray(vidx, dtype=np.int64), z["valid_index"])))
         if epoch in (1, 2, 10):
             for nm, mine in ((f"G_b4_ep{epoch}", G.linears[12].bias), (f"G_temb_ep{epoch}", G.time_embedding.weight),
                              (f"D_b6_ep{epoch}", Dn.linears[6].bias)):
@@ -99,6 +107,8 @@ def test_end_to_end(tmp_path, tag, csv_name):
     # epochs 1 and 2 pin the arithmetic of a training step; by epoch 10 the fp32 summation order of the GEMMs has been
     # amplified (the reference's own runs at different thread counts are 2e-5 apart after TWO epochs,
     # e2e_hospital_spread.json), so that pin only guards against a gross divergence
+    if "valid_rows_differing" in pins:
+        assert pins.pop("valid_rows_differing") <= 40
     for nm, d in pins.items():
         tol = 1e-7 if nm.endswith("ep1") else 1e-6 if nm.endswith("ep2") else 5e-4
         assert d < tol, (nm, d)
