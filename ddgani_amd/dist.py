@@ -60,9 +60,35 @@ class Comm:
         return t
 
 
+# On-chip random numbers are keyed by (seed, stream, LOCAL element index), so what a row draws depends on where its launch
+# starts.  To make throughput-mode results independent of the number of ranks, the table is cut into VSHARDS fixed
+# VIRTUAL shards: every launch that draws covers one virtual shard and carries that shard's number in its stream id, and a
+# rank owns VSHARDS / world consecutive virtual shards -- for world sizes that divide VSHARDS (1, 2, 4, 8: one node) the
+# rows, streams and draws are the same whatever the world size.  Other world sizes fall back to one shard per rank.
+VSHARDS = 8
+
+
+def _even_bounds(N: int, parts: int):
+    per = (N + parts - 1) // parts
+    return [(min(r * per, N), min((r + 1) * per, N)) for r in range(parts)]
+
+
 def shard_bounds(N: int, world: int):
-    per = (N + world - 1) // world
-    return [(min(r * per, N), min((r + 1) * per, N)) for r in range(world)]
+    """rows of every rank: unions of consecutive virtual shards when ``world`` divides VSHARDS"""
+    if VSHARDS % world == 0:
+        vb, g = _even_bounds(N, VSHARDS), VSHARDS // world
+        return [(vb[r * g][0], vb[(r + 1) * g - 1][1]) for r in range(world)]
+    return _even_bounds(N, world)
+
+
+def virtual_pieces(N: int, world: int, rank: int):
+    """[(virtual shard id, lo, hi)] of ``rank``: row ranges RELATIVE to the rank's shard"""
+    if VSHARDS % world != 0:
+        lo, hi = _even_bounds(N, world)[rank]
+        return [(rank, 0, hi - lo)]
+    vb, g = _even_bounds(N, VSHARDS), VSHARDS // world
+    base = vb[rank * g][0]
+    return [(v, vb[v][0] - base, vb[v][1] - base) for v in range(rank * g, (rank + 1) * g) if vb[v][1] > vb[v][0]]
 
 
 def sharded_attn_fill(comm: Comm, backend, X0_local, m_local, W, layout, k: int, N_total: int, out=None):
@@ -77,51 +103,82 @@ def sharded_attn_fill(comm: Comm, backend, X0_local, m_local, W, layout, k: int,
     return backend.attn_topk_fill(X0_local, m_local, X0_local, m_local, W, layout, k, out=out)
 
 
+def _cut(a, lo, hi):
+    return None if a is None else a[lo:hi]
+
+
+def _into(dst, res):
+    """``res`` is what a backend call returned for ``out=dst``: the HIP backend wrote into dst and hands it back (nothing
+    to do), the CPU stand-in of the tests returns a fresh tensor (copy it in)"""
+    if res.data_ptr() != dst.data_ptr():
+        dst.copy_(res)
+
+
 def sharded_denoiser_fwd(comm: Comm, backend, P, x_t, t, layout, N_total: int, drops=None, drop_p: float = 0.2,
-                         seed: int = 0, stream_id: int = 0, row_offset: int = 0, bn_eps: float = 1e-5, out=None):
-    """Generator_x0.forward over a row shard with global (sync) BatchNorm statistics.  ``stream_id`` must already
-    carry the rank (model.Diffusion.stream_of(..., rank=comm.rank)): on-chip dropout is keyed by the LOCAL element
-    index, so shards need distinct streams."""
+                         seed: int = 0, stream_id: int = 0, row_offset: int = 0, bn_eps: float = 1e-5, out=None,
+                         pieces=None, apply_head: bool = True):
+    """Generator_x0.forward over a row shard with global (sync) BatchNorm statistics.  ``pieces``: [(lo, hi, stream_id)]
+    row ranges of the shard with the stream number each one draws its dropout from (the virtual shards of
+    sharded_reverse_sample); default: the whole shard under ``stream_id``."""
     w = P.t
     dev = x_t.device
     d = [None, None, None] if drops is None else drops
+    rows = x_t.shape[0]
+    if pieces is None:
+        pieces = [(0, rows, stream_id)]
     h = x_t
     pro = backend.PRO_ADD_EMB
-    kw = dict(emb=w["time_embedding.weight"], t=t)
+    scale = shift = None
     for l, (li, bi) in enumerate(((0, 1), (4, 5), (8, 9))):
         Wl, bl = w[f"linears.{li}.weight"], w[f"linears.{li}.bias"]
         stats = torch.zeros(2 * Wl.shape[0], dtype=torch.float64, device=dev)
-        z = backend.linear(h, Wl, bl, prologue=pro, stats=stats, **kw)
+        z = torch.empty((rows, Wl.shape[0]), dtype=torch.float32, device=dev)
+        for lo, hi, sid in pieces:
+            if l == 0:
+                kw = dict(emb=w["time_embedding.weight"], t=t if not isinstance(t, torch.Tensor) else t[lo:hi])
+            else:
+                kw = dict(scale=scale, shift=shift, drop=_cut(d[l - 1], lo, hi), drop_p=drop_p, seed=seed,
+                          stream_id=sid * 4 + l - 1)
+            _into(z[lo:hi], backend.linear(h[lo:hi], Wl, bl, prologue=pro, stats=stats, out=z[lo:hi], **kw))
         comm.all_reduce_sum(stats)
         scale, shift = backend.bn_finalize(stats, w[f"linears.{bi}.weight"], w[f"linears.{bi}.bias"], float(N_total),
                                            bn_eps)
         h = z
         pro = backend.PRO_BN_RELU
-        kw = dict(scale=scale, shift=shift, drop=d[l], drop_p=drop_p, seed=seed, stream_id=stream_id * 4 + l)
-    y = backend.linear(h, w["linears.12.weight"], w["linears.12.bias"], prologue=pro, out=out, **kw)
-    return backend.head(y, layout, out=y)
+    y = out if out is not None else torch.empty((rows, w["linears.12.weight"].shape[0]), dtype=torch.float32, device=dev)
+    for lo, hi, sid in pieces:
+        _into(y[lo:hi], backend.linear(h[lo:hi], w["linears.12.weight"], w["linears.12.bias"], prologue=pro, out=y[lo:hi],
+                                       scale=scale, shift=shift, drop=_cut(d[2], lo, hi), drop_p=drop_p, seed=seed,
+                                       stream_id=sid * 4 + 2))
+    return backend.head(y, layout, out=y) if apply_head else y
 
 
 def sharded_reverse_sample(comm: Comm, backend, P, T: int, x, M, layout, N_total: int, randomness=None, seed: int = 0,
                            drop_p: float = 0.2, call: Optional[int] = None):
     """T-step reverse diffusion over a row shard (model/Diffusion.py:426-450), sync-BN across ranks.
-    Random streams follow model.Diffusion.stream_of with this rank in the id; every rank must pass the same
-    ``call`` (default: its own next_call(), equal on all ranks when they make the same calls in the same order)."""
+    On-chip draws: one launch per VIRTUAL shard, whose number (not the rank) goes into the stream id
+    (model.Diffusion.stream_of), so the result does not depend on the world size (1, 2, 4, 8 ranks); every rank must
+    pass the same ``call`` (default: its own next_call(), equal on all ranks when they make the same calls in the same
+    order)."""
     from .model.Diffusion import KIND_DROP, KIND_EPS, KIND_Z, drop_seed, next_call, stream_of
     r = randomness
     call = next_call() if call is None else call
-    rk = comm.rank
-    x_t = backend.forward_noise(x, T, T, eps=None if r is None else r.eps_T, seed=seed,
-                                stream_id=stream_of(call, KIND_EPS, T, rk))
+    vp = virtual_pieces(N_total, comm.world, comm.rank)
+    x_t = torch.empty_like(x)
+    for v, lo, hi in vp:
+        _into(x_t[lo:hi], backend.forward_noise(x[lo:hi], T, T, eps=None if r is None else r.eps_T[lo:hi], seed=seed,
+                                                stream_id=stream_of(call, KIND_EPS, T, v), out=x_t[lo:hi]))
     pred = None
     i = 0
     for ts in range(T, 1, -1):
         pred = sharded_denoiser_fwd(comm, backend, P, x_t, ts, layout, N_total,
                                     drops=None if r is None else r.drops[i], drop_p=drop_p, seed=drop_seed(seed),
-                                    stream_id=stream_of(call, KIND_DROP, ts, rk))
+                                    pieces=[(lo, hi, stream_of(call, KIND_DROP, ts, v)) for v, lo, hi in vp])
         if ts > 2:
-            x_t = backend.reverse_step(x_t, x, M, pred, ts, T, z=None if r is None else r.zs[i], seed=seed,
-                                       stream_id=stream_of(call, KIND_Z, ts, rk), out=x_t)
+            for v, lo, hi in vp:
+                _into(x_t[lo:hi], backend.reverse_step(x_t[lo:hi], x[lo:hi], M[lo:hi], pred[lo:hi], ts, T,
+                                                       z=None if r is None else r.zs[i][lo:hi], seed=seed,
+                                                       stream_id=stream_of(call, KIND_Z, ts, v), out=x_t[lo:hi]))
         i += 1
     return pred
 

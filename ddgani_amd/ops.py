@@ -85,9 +85,9 @@ def schedule_dict(T: int):
 
 # --------------------------------------------------------------------------- a5
 def forward_noise(x0: torch.Tensor, t, T: int, eps: Optional[torch.Tensor] = None, seed: int = 0,
-                  stream_id: int = 0, sched_dev: Optional[torch.Tensor] = None, return_eps: bool = False):
+                  stream_id: int = 0, sched_dev: Optional[torch.Tensor] = None, return_eps: bool = False, out=None):
     rows, D = x0.shape
-    x_t = torch.empty_like(x0)
+    x_t = torch.empty_like(x0) if out is None else out
     eps_out = torch.empty_like(x0) if (return_eps and eps is None) else None
     if isinstance(t, torch.Tensor):
         if sched_dev is None:

@@ -55,7 +55,7 @@ class OracleOps:
     def head(self, y, layout, out=None):
         return self.orc.head(y, layout.offsets, layout.is_cat)
 
-    def forward_noise(self, x0, t, T, eps=None, seed=0, stream_id=0):
+    def forward_noise(self, x0, t, T, eps=None, seed=0, stream_id=0, out=None):
         S = self.orc.schedule(T)
         return self.orc.forward_noise(S, x0, torch.full((x0.shape[0],), t, dtype=torch.long), eps)
 
@@ -160,3 +160,23 @@ def test_shard_bounds_cover_rows():
     for N, w in ((10, 3), (257, 2), (8, 8), (5, 8), (1000000, 8)):
         b = shard_bounds(N, w)
         assert b[0][0] == 0 and b[-1][1] == N and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def test_virtual_shards_partition_rows_identically_for_every_world_size():
+    """ranks own 8 / world consecutive virtual shards: the (virtual shard, global row range) pairs are the same set for
+    world sizes 1, 2, 4, 8, so on-chip draws (keyed by virtual shard and row inside it) do not depend on the world size"""
+    sys.path.insert(0, ROOT)
+    from ddgani_amd import dist as ddist
+    for N in (1, 7, 8, 30_001, 1_000_000):
+        ref = None
+        for world in (1, 2, 4, 8):
+            bounds = ddist.shard_bounds(N, world)
+            assert bounds[0][0] == 0 and bounds[-1][1] == N and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+            pieces = []
+            for r in range(world):
+                for v, lo, hi in ddist.virtual_pieces(N, world, r):
+                    pieces.append((v, bounds[r][0] + lo, bounds[r][0] + hi))
+            ref = ref or pieces
+            assert pieces == ref, (N, world)
+    # a world size that does not divide 8: one piece per rank, the rank as its number
+    assert ddist.virtual_pieces(100, 3, 1) == [(1, 0, 34)]
