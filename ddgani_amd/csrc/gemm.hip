@@ -126,6 +126,53 @@ __device__ __forceinline__ f32x4 lin_stage_b(const LinArgs &p, int n, int k0, bo
     return bv;
 }
 
+// k_linear_wide splits lin_stage_a's fast path in two, so that the global loads of a chunk are ISSUED a whole chunk before
+// anything depends on them: lin_raw_a = the loads (operand, embedding row / BatchNorm scale and shift of the same four
+// columns), lin_finish_a = the prologue arithmetic on the loaded values (same expressions as lin_stage_a: bit-identical).
+struct LinRaw {
+    f32x4 a, e0, e1;      // operand; embedding row (ADD_EMB / EMB_RELU) or BatchNorm scale (BN_RELU); BatchNorm shift
+    uint32_t mk;          // explicit dropout mask bytes (BN_RELU with p.drop)
+};
+template <int PRO>
+__device__ __forceinline__ void lin_raw_a(const LinArgs &p, int64_t row, int k0, int trow, LinRaw &r) {
+    r.a = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.e0 = r.a; r.e1 = r.a; r.mk = 0;
+    if (row >= p.rows || k0 >= p.in) return;
+    r.a = *reinterpret_cast<const f32x4 *>(p.A + row * p.in + k0);
+    if (PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) {
+        r.e0 = *reinterpret_cast<const f32x4 *>(p.emb + (int64_t)trow * p.in + k0);
+    } else if (PRO == DDG_PRO_BN_RELU) {
+        r.e0 = *reinterpret_cast<const f32x4 *>(p.scale + k0);
+        r.e1 = *reinterpret_cast<const f32x4 *>(p.shift + k0);
+        if (p.drop) r.mk = *reinterpret_cast<const uint32_t *>(p.drop + row * p.in + k0);
+    }
+}
+template <int PRO>
+__device__ __forceinline__ f32x4 lin_finish_a(const LinArgs &p, const LinRaw &r, int64_t row, int k0, float keep_scale) {
+    f32x4 av = r.a;
+    if (row >= p.rows || k0 >= p.in) return f32x4{0.f, 0.f, 0.f, 0.f};
+    if (PRO == DDG_PRO_ADD_EMB || PRO == DDG_PRO_EMB_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            av[e] += r.e0[e];
+            if (PRO == DDG_PRO_EMB_RELU) av[e] = fmaxf(av[e], 0.f);
+        }
+    } else if (PRO == DDG_PRO_BN_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = fmaxf(av[e] * r.e0[e] + r.e1[e], 0.f);
+        if (p.drop) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = ((r.mk >> (8 * e)) & 0xffu) ? av[e] * keep_scale : 0.f;
+        } else if (p.drop_p > 0.f) {
+            const uint64_t e0 = (uint64_t)row * (uint64_t)p.in + (uint64_t)k0;
+            const f32x4 u = philox_uniform4(p.seed, p.stream_id, e0 >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[e] = (u[e] > p.drop_p) ? av[e] * keep_scale : 0.f;
+        }
+    }
+    return av;
+}
+
 // epilogue shared by both kernels: + bias, store, fp64 column statistics
 #define LIN_EPILOGUE(VAL)                                                                                       \
     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                          \
@@ -460,12 +507,15 @@ __global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
                 trows[i] = min(max(p.t ? (int)p.t[row] : p.t_uniform, 0), p.emb_rows - 1);
         }
 
-        f32x4 pa[NPA], pb[PS ? 1 : NPB];
+        LinRaw pa[NPA];
+        f32x4 pb[PS ? 1 : NPB];
         f16x4 pbh[PS ? NPB : 1], pbl[PS ? NPB : 1];
+        int k0_held = 0;                            // first column of the chunk held in pa / pb
         auto fetch = [&](int chunk) {
             const int k0 = chunk * KCH + st_c4 * 4;
+            k0_held = k0;
 #pragma unroll
-            for (int i = 0; i < NPA; ++i) pa[i] = lin_stage_a<PRO>(p, row0 + st_r + 64 * i, k0, trows[i], keep_scale, true);
+            for (int i = 0; i < NPA; ++i) lin_raw_a<PRO>(p, row0 + st_r + 64 * i, k0, trows[i], pa[i]);
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
                 if constexpr (PS) {
@@ -488,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void k_linear_wide(LinArgs p) {
 #pragma unroll
             for (int i = 0; i < NPA; ++i) {
                 const int rl = st_r + 64 * i;
-                split4(pa[i], hi, lo);
+                split4(lin_finish_a<PRO>(p, pa[i], row0 + rl, k0_held, keep_scale), hi, lo);
                 *reinterpret_cast<f16x4 *>(&As[rl * SSTR + st_c4 * 8]) = hi;
                 *reinterpret_cast<f16x4 *>(&As[rl * SSTR + 2 * KCH + st_c4 * 8]) = lo;
             }
