@@ -8,6 +8,7 @@
 //   Generator_x0 head              model/Diffusion.py:188-201
 //   mask-merge + re-softmax        model/Diffusion.py:598, :606-615
 #include <math.h>
+#include <type_traits>
 #include "common.h"
 
 extern "C" int ddg_version(void) { return 100; }
@@ -108,9 +109,12 @@ __global__ void k_forward_noise_rows(const float *__restrict__ x0, const float *
     }
 }
 
+#define EW_GRID_MAX ((int64_t)1 << 30)
 static inline int ew_grid(int64_t work_items, int block) {
+    // one work item per thread, no persistent loop: measured on this chip (scratch stream_bench, 4 streams in / 1 out,
+    // 704 MB each) a full grid streams at 5.6 TB/s, 4 096 grid-striding workgroups at 4.3 (a plain copy: 6.2 vs 4.7)
     int64_t g = ceil_div64(work_items, block);
-    if (g > 256 * 16) g = 256 * 16;
+    if (g > EW_GRID_MAX) g = EW_GRID_MAX;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -200,6 +204,69 @@ extern "C" int ddg_reverse_step(const float *x_t, const float *x, const float *M
 // a6 head / a9 mask-merge: a block stages ROWS_PB rows in LDS (coalesced), one thread per
 // (row, field) applies sigmoid / softmax over the field's block, then the rows go back coalesced.
 // ---------------------------------------------------------------------------------------------
+// Field lists of a head kernel in LDS, built once per workgroup: the categorical fields (their softmax needs the whole
+// block: one thread per (row, field)) and the numeric COLUMNS (one thread per (row, column) applies the sigmoid in the
+// tile).  A sigmoid evaluated per element and selected away on categorical elements cost an expf and an IEEE division
+// on every element of a table that is mostly one-hot blocks (c3: 128 of 176 columns).
+struct HeadLists { uint16_t *numc; int *catf; int *cnt; };
+__device__ __forceinline__ HeadLists head_lists_at(float *after_tile, int D, int C) {
+    HeadLists h;
+    h.numc = reinterpret_cast<uint16_t *>(after_tile);                                     // [D]
+    h.catf = reinterpret_cast<int *>(after_tile + ((D + 1) >> 1));                          // [C]
+    h.cnt = h.catf + C;                                                                     // [2]: ncat, nnum
+    return h;
+}
+// Built by the first wave alone, positions from ballots and a wave scan: no LDS atomics and no barrier of its own -- the
+// caller's barrier after the tile load publishes the lists, and the (L2-resident) reads of offsets / is_cat overlap with
+// the tile's loads.  Lists come out in field order.
+__device__ __forceinline__ void head_lists_build(const HeadLists &h, const int32_t *offsets, const uint8_t *is_cat, int C) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    int ncat = 0, nnum = 0;
+    for (int f0 = 0; f0 < C; f0 += 64) {
+        const int f = f0 + lane;
+        const bool valid = f < C;
+        const bool ic = valid && is_cat[f];
+        const int a = valid ? offsets[f] : 0, wdt = (valid && !ic) ? offsets[f + 1] - a : 0;
+        const uint64_t m = __ballot(ic);
+        if (ic) h.catf[ncat + __popcll(m & ((1ull << lane) - 1))] = f;
+        ncat += __popcll(m);
+        int incl = wdt;                                   // inclusive scan of the numeric widths over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        for (int j = 0; j < wdt; ++j) h.numc[nnum + incl - wdt + j] = (uint16_t)(a + j);
+        nnum += __shfl(incl, 63);
+    }
+    if (lane == 0) { h.cnt[0] = ncat; h.cnt[1] = nnum; }
+}
+// w / n for 0 <= w < 2^16 without an integer division: (w + 0.5) / n is at least 0.5 / n away from an integer, far more
+// than the product's rounding error
+__device__ __forceinline__ int div_small(int w, float inv_n) { return (int)(((float)w + 0.5f) * inv_n); }
+__device__ __forceinline__ float sigmoid_ref(float v) { return 1.f / (1.f + expf(-v)); }
+// the two in-tile phases of a head: softmax over every categorical block, sigmoid of every numeric column (the numeric
+// phase only when the table has categorical fields: an all-numeric table applies the sigmoid where the element is used)
+__device__ __forceinline__ void head_in_tile(float *tile, const HeadLists &h, const int32_t *offsets, int nr, int D,
+                                             bool sigmoid_phase) {
+    const int ncat = h.cnt[0], nnum = h.cnt[1];
+    const float inv_ncat = 1.f / (float)(ncat > 0 ? ncat : 1), inv_nnum = 1.f / (float)(nnum > 0 ? nnum : 1);
+    for (int w = threadIdx.x; w < nr * ncat; w += blockDim.x) {
+        const int r = div_small(w, inv_ncat), f = h.catf[w - r * ncat];
+        const int a = offsets[f], b = offsets[f + 1];
+        float *p = tile + r * D;
+        float mx = p[a];
+        for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
+        float s = 0.f;
+        for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
+        for (int j = a; j < b; ++j) p[j] = p[j] / s;
+    }
+    if (sigmoid_phase)
+        for (int w = threadIdx.x; w < nr * nnum; w += blockDim.x) {
+            const int r = div_small(w, inv_nnum);
+            float *p = tile + r * D + h.numc[w - r * nnum];
+            *p = sigmoid_ref(*p);
+        }
+}
+
 template <bool MERGE>
 __global__ void k_head_merge(const float *__restrict__ y, const float *__restrict__ x, const float *__restrict__ M,
                              const int32_t *__restrict__ offsets, const uint8_t *__restrict__ is_cat, int C,
@@ -207,26 +274,26 @@ __global__ void k_head_merge(const float *__restrict__ y, const float *__restric
     // as in k_head_reverse: the (row, field) phase only for the categorical fields; a numeric element's sigmoid is
     // applied where the element is written back
     extern __shared__ float tile[];
-    uint8_t *kind = reinterpret_cast<uint8_t *>(tile + (size_t)rows_pb * D);      // [D] 1: element of a categorical field
-    int *catf = reinterpret_cast<int *>(kind + ((D + 3) & ~3));                     // [C] the categorical fields
-    __shared__ int s_ncat;
-    if (threadIdx.x == 0) s_ncat = 0;
-    __syncthreads();
-    for (int f = threadIdx.x; f < C; f += blockDim.x) {
-        const uint8_t ic = is_cat[f];
-        if (ic) catf[atomicAdd(&s_ncat, 1)] = f;
-        for (int j = offsets[f]; j < offsets[f + 1]; ++j) kind[j] = ic;
-    }
-    __syncthreads();
-    const int ncat = s_ncat;
+    const HeadLists h = head_lists_at(tile + (size_t)rows_pb * D, D, C);
+    head_lists_build(h, offsets, is_cat, C);               // published by the first tile's barrier
     const int64_t nblk = ceil_div64(rows, rows_pb);
-    const int cstep = (int)(blockDim.x % (unsigned)D);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t r0 = blk * rows_pb;
         const int nr = (int)((rows - r0 < rows_pb) ? rows - r0 : rows_pb);
         const int64_t base = r0 * D;
         const int nel = nr * D;
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+        const int n4 = (base & 3) == 0 ? nel >> 2 : 0;          // 16-byte accesses where the tile starts aligned
+        for (int g = threadIdx.x; g < n4; g += blockDim.x) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(y + base + 4 * g);
+            if (MERGE) {
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(M + base + 4 * g);
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + base + 4 * g);
+                v.x = m.x * xv.x + (1.f - m.x) * v.x; v.y = m.y * xv.y + (1.f - m.y) * v.y;
+                v.z = m.z * xv.z + (1.f - m.z) * v.z; v.w = m.w * xv.w + (1.f - m.w) * v.w;
+            }
+            *reinterpret_cast<f32x4 *>(tile + 4 * g) = v;
+        }
+        for (int i = 4 * n4 + threadIdx.x; i < nel; i += blockDim.x) {
             float v = y[base + i];
             if (MERGE) {
                 const float m = M[base + i];
@@ -235,28 +302,15 @@ __global__ void k_head_merge(const float *__restrict__ y, const float *__restric
             tile[i] = v;
         }
         __syncthreads();
-        for (int w = threadIdx.x; w < nr * ncat; w += blockDim.x) {
-            const int r = w / ncat, f = catf[w - r * ncat];
-            const int a = offsets[f], b = offsets[f + 1];
-            float *p = tile + r * D;
-            float mx = p[a];
-            for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
-            float s = 0.f;
-            for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
-            for (int j = a; j < b; ++j) p[j] = p[j] / s;
-        }
+        const bool inline_sigmoid = !MERGE && h.cnt[0] == 0;   // all-numeric table: sigmoid where the element is written back
+        head_in_tile(tile, h, offsets, nr, D, !MERGE && !inline_sigmoid);
         __syncthreads();
-        int col = threadIdx.x % D;                       // column of element i (the tile starts at a row start)
-        for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-            float v = tile[i];
-            if (!MERGE) {
-                const float sg = 1.f / (1.f + expf(-v));
-                v = kind[col] ? v : sg;
-            }
-            out[base + i] = v;
-            col += cstep;
-            if (col >= D) col -= D;
+        for (int g = threadIdx.x; g < n4; g += blockDim.x) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(tile + 4 * g);
+            if (inline_sigmoid) { v.x = sigmoid_ref(v.x); v.y = sigmoid_ref(v.y); v.z = sigmoid_ref(v.z); v.w = sigmoid_ref(v.w); }
+            *reinterpret_cast<f32x4 *>(out + base + 4 * g) = v;
         }
+        for (int i = 4 * n4 + threadIdx.x; i < nel; i += blockDim.x) out[base + i] = inline_sigmoid ? sigmoid_ref(tile[i]) : tile[i];
         __syncthreads();
     }
 }
@@ -271,26 +325,47 @@ __global__ void k_head_reverse(const float *__restrict__ y, const float *__restr
                                uint64_t stream_id, const int32_t *__restrict__ offsets,
                                const uint8_t *__restrict__ is_cat, int C, float *__restrict__ out, int64_t rows, int D,
                                int rows_pb) {
-    // Work split without divergence: only the categorical fields go through a (row, field) phase -- their softmax needs
-    // the whole block; the sigmoid of a numeric element is applied where the element is consumed, in the elementwise
-    // reverse-step phase (one thread per (row, field) over ALL fields made every wave run the 8-element softmax path and
-    // the sigmoid path one after the other: 0.35 of the HBM rate).  Same expressions per element: bit-identical results.
+    // Work split without divergence: the categorical fields go through a (row, field) phase -- their softmax needs the
+    // whole block -- and the numeric columns through a (row, column) phase (head_in_tile); one thread per (row, field)
+    // over ALL fields made every wave run the 8-element softmax path and the sigmoid path one after the other (0.35 of
+    // the HBM rate), a sigmoid per element selected away on categorical ones wasted an expf and a division on most of
+    // c3's columns.  Same expressions per element: bit-identical results.
     extern __shared__ float tile[];
-    uint8_t *kind = reinterpret_cast<uint8_t *>(tile + (size_t)rows_pb * D);      // [D] 1: element of a categorical field
-    int *catf = reinterpret_cast<int *>(kind + ((D + 3) & ~3));                     // [C] the categorical fields
-    __shared__ int s_ncat;
-    if (threadIdx.x == 0) s_ncat = 0;
-    __syncthreads();
-    for (int f = threadIdx.x; f < C; f += blockDim.x) {
-        const uint8_t ic = is_cat[f];
-        if (ic) catf[atomicAdd(&s_ncat, 1)] = f;
-        for (int j = offsets[f]; j < offsets[f + 1]; ++j) kind[j] = ic;
-    }
-    __syncthreads();
-    const int ncat = s_ncat;
-    auto pred_of = [&](float v, int col) {           // (unconditional sigmoid + select: no divergent region per element)
-        const float sg = 1.f / (1.f + expf(-v));
-        return kind[col] ? v : sg;
+    const HeadLists h = head_lists_at(tile + (size_t)rows_pb * D, D, C);
+    head_lists_build(h, offsets, is_cat, C);               // published by the first tile's barrier
+    // the elementwise phase, compiled twice: with the sigmoid applied where the element is consumed (all-numeric tables)
+    // and without (the tile already holds the head's output)
+    auto reverse_phase = [&](auto SIG, int64_t base, int nel) {
+        constexpr bool sig = decltype(SIG)::value;
+        auto pred_of = [&](float v) { return sig ? sigmoid_ref(v) : v; };
+        if ((base & 3) == 0) {
+            const int ng = (nel + 3) / 4;
+            for (int g = threadIdx.x; g < ng; g += blockDim.x) {
+                const int i0 = g * 4;
+                const int64_t e0 = base + i0;
+                if (i0 + 3 < nel) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(xt + e0);
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(x + e0);
+                    const f32x4 m = *reinterpret_cast<const f32x4 *>(M + e0);
+                    const f32x4 zz = z ? *reinterpret_cast<const f32x4 *>(z + e0) : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
+                    const f32x4 pv = *reinterpret_cast<const f32x4 *>(tile + i0);
+                    f32x4 r;
+                    r.x = rev_one(a.x, b.x, m.x, pred_of(pv.x), zz.x, k); r.y = rev_one(a.y, b.y, m.y, pred_of(pv.y), zz.y, k);
+                    r.z = rev_one(a.z, b.z, m.z, pred_of(pv.z), zz.z, k); r.w = rev_one(a.w, b.w, m.w, pred_of(pv.w), zz.w, k);
+                    *reinterpret_cast<f32x4 *>(out + e0) = r;
+                } else {
+                    const f32x4 z4 = z ? f32x4{0, 0, 0, 0} : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
+                    for (int c = 0; c < 4 && i0 + c < nel; ++c)
+                        out[e0 + c] = rev_one(xt[e0 + c], x[e0 + c], M[e0 + c], pred_of(tile[i0 + c]), z ? z[e0 + c] : z4[c], k);
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+                const int64_t e = base + i;
+                const float zz = z ? z[e] : philox_normal4(seed, stream_id, (uint64_t)(e >> 2))[e & 3];
+                out[e] = rev_one(xt[e], x[e], M[e], pred_of(tile[i]), zz, k);
+            }
+        }
     };
     const int64_t nblk = ceil_div64(rows, rows_pb);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -307,52 +382,11 @@ __global__ void k_head_reverse(const float *__restrict__ y, const float *__restr
             for (int i = threadIdx.x; i < nel; i += blockDim.x) tile[i] = y[base + i];
         }
         __syncthreads();
-        for (int w = threadIdx.x; w < nr * ncat; w += blockDim.x) {
-            const int r = w / ncat, f = catf[w - r * ncat];
-            const int a = offsets[f], b = offsets[f + 1];
-            float *p = tile + r * D;
-            float mx = p[a];
-            for (int j = a + 1; j < b; ++j) mx = fmaxf(mx, p[j]);
-            float s = 0.f;
-            for (int j = a; j < b; ++j) { const float e = expf(p[j] - mx); p[j] = e; s += e; }
-            for (int j = a; j < b; ++j) p[j] = p[j] / s;
-        }
+        const bool inline_sigmoid = h.cnt[0] == 0;
+        head_in_tile(tile, h, offsets, nr, D, !inline_sigmoid);
         __syncthreads();
-        if ((base & 3) == 0) {
-            const int ng = (nel + 3) / 4;
-            const int cstep = (int)((4 * blockDim.x) % (unsigned)D);
-            int col = (4 * threadIdx.x) % D;             // column of element i0 (the tile starts at a row start)
-            for (int g = threadIdx.x; g < ng; g += blockDim.x) {
-                const int i0 = g * 4;
-                const int64_t e0 = base + i0;
-                int cc[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) cc[c] = col + c < D ? col + c : col + c - D;
-                if (i0 + 3 < nel) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(xt + e0);
-                    const f32x4 b = *reinterpret_cast<const f32x4 *>(x + e0);
-                    const f32x4 m = *reinterpret_cast<const f32x4 *>(M + e0);
-                    const f32x4 zz = z ? *reinterpret_cast<const f32x4 *>(z + e0) : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
-                    const f32x4 pv = *reinterpret_cast<const f32x4 *>(tile + i0);
-                    f32x4 r;
-                    r.x = rev_one(a.x, b.x, m.x, pred_of(pv.x, cc[0]), zz.x, k); r.y = rev_one(a.y, b.y, m.y, pred_of(pv.y, cc[1]), zz.y, k);
-                    r.z = rev_one(a.z, b.z, m.z, pred_of(pv.z, cc[2]), zz.z, k); r.w = rev_one(a.w, b.w, m.w, pred_of(pv.w, cc[3]), zz.w, k);
-                    *reinterpret_cast<f32x4 *>(out + e0) = r;
-                } else {
-                    const f32x4 z4 = z ? f32x4{0, 0, 0, 0} : philox_normal4(seed, stream_id, (uint64_t)(e0 >> 2));
-                    for (int c = 0; c < 4 && i0 + c < nel; ++c)
-                        out[e0 + c] = rev_one(xt[e0 + c], x[e0 + c], M[e0 + c], pred_of(tile[i0 + c], cc[c]), z ? z[e0 + c] : z4[c], k);
-                }
-                col += cstep;
-                if (col >= D) col -= D;
-            }
-        } else {
-            for (int i = threadIdx.x; i < nel; i += blockDim.x) {
-                const int64_t e = base + i;
-                const float zz = z ? z[e] : philox_normal4(seed, stream_id, (uint64_t)(e >> 2))[e & 3];
-                out[e] = rev_one(xt[e], x[e], M[e], pred_of(tile[i], i % D), zz, k);
-            }
-        }
+        if (inline_sigmoid) reverse_phase(std::true_type{}, base, nel);
+        else reverse_phase(std::false_type{}, base, nel);
         __syncthreads();
     }
 }
@@ -386,9 +420,9 @@ extern "C" int ddg_head_reverse_step(const float *y, const float *x_t, const flo
     if (rows_pb < 1) rows_pb = 8192 / D;
     if (rows_pb < 1) return DDG_E_UNSUPPORTED;
     if (rows_pb > 64) rows_pb = 64;
-    const size_t lds = (size_t)rows_pb * D * sizeof(float) + ((D + 3) & ~3) + (size_t)C * sizeof(int);
+    const size_t lds = (size_t)rows_pb * D * sizeof(float) + (size_t)((D + 1) >> 1) * 4 + (size_t)(C + 2) * sizeof(int);
     const int64_t nblk = ceil_div64(rows, rows_pb);
-    const int grid = (int)(nblk < 256 * 16 ? nblk : 256 * 16);
+    const int grid = (int)(nblk < EW_GRID_MAX ? nblk : EW_GRID_MAX);      // one tile per workgroup (see ew_grid)
     k_head_reverse<<<grid, 256, lds, (hipStream_t)stream>>>(y, x_t, x, M, z, k, seed, stream_id, offsets, is_cat, C, out,
                                                             rows, D, rows_pb);
     DDG_CHECK_LAUNCH();
@@ -405,9 +439,9 @@ static int launch_head_merge(bool merge, const float *y, const float *x, const f
     if (rows_pb > 64) rows_pb = 64;
     // a minibatch (B = 128) would fill three workgroups: fewer rows per workgroup until about 512 of them exist
     if (rows < (int64_t)512 * rows_pb) rows_pb = (int)(rows / 512 > 1 ? rows / 512 : 1);
-    const size_t lds = (size_t)rows_pb * D * sizeof(float) + ((D + 3) & ~3) + (size_t)C * sizeof(int);
+    const size_t lds = (size_t)rows_pb * D * sizeof(float) + (size_t)((D + 1) >> 1) * 4 + (size_t)(C + 2) * sizeof(int);
     int64_t nblk = ceil_div64(rows, rows_pb);
-    int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    int grid = (int)(nblk < EW_GRID_MAX ? nblk : EW_GRID_MAX);
     if (merge)
         k_head_merge<true><<<grid, 256, lds, (hipStream_t)stream>>>(y, x, M, offsets, is_cat, C, out, rows, D, rows_pb);
     else
