@@ -122,8 +122,9 @@ static inline int ew_grid(int64_t work_items, int block) {
 extern "C" int ddg_forward_noise(const float *x0, const float *eps, const int64_t *t, int t_uniform,
                                  const float *sched, int T, uint64_t seed, uint64_t stream_id, float *x_t,
                                  float *eps_out, int64_t rows, int D, void *stream) {
-    if (!x0 || !x_t || rows < 0 || D < 1 || T < 1) return DDG_E_ARG;
-    if (rows == 0) return DDG_OK;
+    if (rows < 0 || D < 1 || T < 1) return DDG_E_ARG;
+    if (rows == 0) return DDG_OK;                       // an empty table: nothing to launch, data pointers may be NULL
+    if (!x0 || !x_t) return DDG_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = rows * D;
     if (t) {
@@ -189,7 +190,8 @@ static inline int rev_coef_of(const float *sh, int T, int t, RevCoef &k) { retur
 extern "C" int ddg_reverse_step(const float *x_t, const float *x, const float *M, const float *pred, const float *z,
                                 const float *sh, int T, int t, uint64_t seed, uint64_t stream_id, float *out,
                                 int64_t rows, int D, void *stream) {
-    if (!x_t || !x || !M || !pred || !sh || !out || rows < 0 || D < 1) return DDG_E_ARG;
+    if (!sh || rows < 0 || D < 1) return DDG_E_ARG;
+    if (rows > 0 && (!x_t || !x || !M || !pred || !out)) return DDG_E_ARG;
     RevCoef k;
     int rc = rev_coef_of(sh, T, t, k);
     if (rc) return rc;
@@ -408,7 +410,8 @@ extern "C" int ddg_head_reverse_step(const float *y, const float *x_t, const flo
                                      const float *sh, int T, int t, uint64_t seed, uint64_t stream_id,
                                      const int32_t *offsets, const uint8_t *is_cat, int C, float *out, int64_t rows,
                                      int D, void *stream) {
-    if (!y || !x_t || !x || !M || !sh || !offsets || !is_cat || !out || rows < 0 || D < 1 || C < 1) return DDG_E_ARG;
+    if (!sh || !offsets || !is_cat || rows < 0 || D < 1 || C < 1) return DDG_E_ARG;
+    if (rows > 0 && (!y || !x_t || !x || !M || !out)) return DDG_E_ARG;
     RevCoef k;
     int rc = rev_coef(sh, T, t, k);
     if (rc) return rc;
@@ -431,9 +434,9 @@ extern "C" int ddg_head_reverse_step(const float *y, const float *x_t, const flo
 
 static int launch_head_merge(bool merge, const float *y, const float *x, const float *M, const int32_t *offsets,
                              const uint8_t *is_cat, int C, float *out, int64_t rows, int D, void *stream) {
-    if (!y || !offsets || !is_cat || !out || rows < 0 || D < 1 || C < 1) return DDG_E_ARG;
-    if (merge && (!x || !M)) return DDG_E_ARG;
-    if (rows == 0) return DDG_OK;
+    if (!offsets || !is_cat || rows < 0 || D < 1 || C < 1) return DDG_E_ARG;
+    if (rows == 0) return DDG_OK;                       // an empty table: data pointers may be NULL
+    if (!y || !out || (merge && (!x || !M))) return DDG_E_ARG;
     int rows_pb = 8192 / D;            // <= 32 KiB of LDS
     if (rows_pb < 1) return DDG_E_UNSUPPORTED;
     if (rows_pb > 64) rows_pb = 64;

@@ -832,7 +832,8 @@ static int linear_impl(const float *A, const float *A2, int in1, const float *W,
                        const float *shift, const uint8_t *drop, float drop_p, uint64_t seed, uint64_t stream_id, float *Y,
                        double *stats, int64_t rows, int in, int out, void *stream, _Float16 *wsplit = nullptr) {
     // wsplit: scratch of 2 * out * in f16 for the pre-split weights of the wide kernel, or null (split per tile)
-    if (!A || !W || !bias || !Y || rows < 0 || in < 1 || out < 1) return DDG_E_ARG;
+    if (!W || !bias || rows < 0 || in < 1 || out < 1) return DDG_E_ARG;
+    if (rows > 0 && (!A || !Y)) return DDG_E_ARG;       // (an empty batch: nothing is launched, A / Y may be NULL)
     if (A2 ? (in1 < 1 || in1 >= in) : (in1 != in)) return DDG_E_ARG;
     if ((prologue == DDG_PRO_ADD_EMB || prologue == DDG_PRO_EMB_RELU) && !emb) return DDG_E_ARG;
     if (prologue == DDG_PRO_BN_RELU && (!scale || !shift)) return DDG_E_ARG;

@@ -16,6 +16,9 @@
  *  - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
  *    default stream); no entry point synchronises;
  *  - matrices are row-major contiguous fp32 unless stated otherwise;
+ *  - an empty table (rows == 0 / Nq == 0) returns DDG_OK without a launch; the elementwise, head and
+ *    ddg_linear entry points then accept NULL for the row-data pointers (torch hands out NULL for
+ *    empty tensors), all other arguments are still checked;
  *  - "field layout": a table column c occupies encoded columns [offsets[c], offsets[c+1])
  *    (width 1 = numeric, width > 1 = one-hot categorical); offsets is int32[C+1] on the
  *    DEVICE, D = offsets[C];  is_cat is uint8[C] on the DEVICE.

@@ -130,3 +130,39 @@ def test_fused_head_reverse_step_is_bit_identical(widths):
     xt2 = x_t.clone()
     ops.head_reverse_step(y, xt2, x, M, T, T, lay, z=z, out=xt2)
     assert torch.equal(xt2, ops.reverse_step(x_t, x, M, ops.head(y, lay), T, T, z=z))
+
+
+@pytest.mark.parametrize("widths", [[1, 1, 5, 1, 3, 1, 1, 8, 1], [1] * 177, [4] * 36 + [1] * 5, [7, 1, 2], [3] * 59])
+@pytest.mark.parametrize("rows", [0, 1, 63, 5003])
+def test_head_and_mask_merge_against_torch(widths, rows):
+    """ddg_head / ddg_mask_merge (model/Diffusion.py:189-201, :598-615) against the same torch ops in fp32 on the device:
+    sigmoid on numeric columns, softmax over every categorical block, the observed cells of x kept; tile starts that are
+    and are not 16-byte aligned (D = 177, 9), tables with no numeric / no categorical column, empty and one-row inputs."""
+    from ddgani_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(len(widths) + rows)
+    lay = ops.FieldLayout(widths, dev)
+    D = lay.D
+    y = (torch.randn(rows, D, generator=g) * 3).to(dev)
+    x = torch.rand(rows, D, generator=g).to(dev)
+    M = (torch.rand(rows, D, generator=g) < 0.6).float().to(dev)
+
+    def head_ref(v):
+        out = torch.empty_like(v)
+        for c, w in enumerate(widths):
+            a, b = lay.offsets[c], lay.offsets[c + 1]
+            out[:, a:b] = torch.softmax(v[:, a:b], dim=1) if w > 1 else torch.sigmoid(v[:, a:b])
+        return out
+
+    got = ops.head(y, lay)
+    assert got.shape == (rows, D)
+    if rows:
+        assert float((got - head_ref(y)).abs().max()) <= 3e-7
+    merged = ops.mask_merge(x, M, y, lay)
+    if rows:
+        want = M * x + (1 - M) * y
+        for c, w in enumerate(widths):
+            if w > 1:
+                a, b = lay.offsets[c], lay.offsets[c + 1]
+                want[:, a:b] = torch.softmax(want[:, a:b], dim=1)
+        assert float((merged - want).abs().max()) <= 3e-7
