@@ -34,7 +34,7 @@ from util_golden import GOLD, load
 pytestmark = pytest.mark.gpu
 
 
-def _run_pipeline(tmp_path, tag, csv_name, rng="host", epochs=None):
+def _run_pipeline(tmp_path, tag, csv_name, rng="host", epochs=None, attn_from_reference=False):
     from ddgani_amd.BaseLine import DiffGANI
     from ddgani_amd.utils import util
     from ddgani_amd.utils.data_loader import data_loader, set_label, value_loader
@@ -69,23 +69,49 @@ def _run_pipeline(tmp_path, tag, csv_name, rng="host", epochs=None):
             for nm, mine in ((f"G_b4_ep{epoch}", G.linears[12].bias), (f"G_temb_ep{epoch}", G.time_embedding.weight),
                              (f"D_b6_ep{epoch}", Dn.linears[6].bias)):
                 pins[nm] = float(np.abs(mine.detach().cpu().numpy() - z[nm]).max())
-    fill = DiffGANI.get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, param["categorical_cols"],
-                                      continuous_cols, value_cat, torch.device("cuda:0"), param, label_data, values,
-                                      ori_data, label_num, args, rng=rng, log=log,
-                                      epoch_hook=hook if rng == "host" else None)
+    own_attn = []
+    orig_attn = DiffGANI.init_attn_2
+    if attn_from_reference:
+        # the attention stage runs and is compared as usual, but the diffusion stage is fed the table the REFERENCE's
+        # attention stage produced: where near-tie cells legitimately differ (adult), the training-trajectory pins then
+        # test the training arithmetic on identical inputs
+        def patched(*a, **k):
+            df, code = orig_attn(*a, **k)
+            own_attn.append(df.copy())
+            ref = pd.DataFrame(z["attn_coded"], columns=values)
+            ref[value_cat] = enc.inverse_transform(ref[value_cat])
+            for c in values:
+                if c not in value_cat:
+                    ref[c] = ref[c].astype(df[c].dtype)
+            return ref, code
+        DiffGANI.init_attn_2 = patched
+    try:
+        fill = DiffGANI.get_Diff_acc_RMSE(nan_data, path, miss_rate, miss_data, enc, data_m, param["categorical_cols"],
+                                          continuous_cols, value_cat, torch.device("cuda:0"), param, label_data, values,
+                                          ori_data, label_num, args, rng=rng, log=log,
+                                          epoch_hook=hook if rng == "host" else None)
+    finally:
+        DiffGANI.init_attn_2 = orig_attn
     fill_df = pd.DataFrame(fill, columns=values)
     final = util.errorLoss(fill_df, ori_data, data_m, value_cat, continuous_cols, enc)
-    attn = pd.read_csv(path + f"Attention_Input_miss_data_{miss_rate}.csv")
+    attn = own_attn[0] if own_attn else pd.read_csv(path + f"Attention_Input_miss_data_{miss_rate}.csv")
     if value_cat:
         attn[value_cat] = enc.transform(attn[value_cat])
     return z, data_m, attn.values.astype(float), log, final, continuous_cols, pins
 
 
-@pytest.mark.parametrize("tag,csv_name", [("e2e_hospital", "hospital.csv"), ("e2e_wine_MNAR", "wine.csv")])
+@pytest.mark.parametrize("tag,csv_name", [("e2e_hospital", "hospital.csv"), ("e2e_wine_MNAR", "wine.csv"),
+                                          ("e2e_adult", "adult.csv")])
 def test_end_to_end(tmp_path, tag, csv_name):
     """hospital: 9 columns, 7 categorical (one-hot heavy), MCAR 0.2, fallback validation split;
-    wine: 13 numeric columns, MNAR (BASELINE.json config 2 style), 142 rows."""
-    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, tag, csv_name)
+    wine: 13 numeric columns, MNAR (BASELINE.json config 2 style), 142 rows;
+    adult: BASELINE.json configs[0] at its full size -- 24 118 rows after the train split, 14 columns (8 categorical,
+    D = 118), MCAR 0.2, top_k 0.05 (k = 1 205: the window selection on a real table), Learner on the income label, FD
+    plug-in on education / education-num, fallback validation split (tests/golden/make_e2e_adult.py).  About 1 % of
+    adult's attention-filled numeric cells are near-ties on which the reference's fp32 rounding decides (adjudicated in
+    test_adult_attention_cells_adjudicated), so its diffusion stage is run on the reference's attention table: the
+    trajectory pins and scores then compare the training / sampling arithmetic on identical inputs."""
+    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, tag, csv_name, attn_from_reference=tag == "e2e_adult")
     assert np.array_equal(np.asarray(data_m), z["data_m"])
     # attention fill: numeric cells to 1e-4 relative; categorical cells (arg-max of a softmax-weighted
     # vote) may flip only on near-ties
@@ -96,8 +122,12 @@ def test_end_to_end(tmp_path, tag, csv_name):
         # logits, and the reference thresholds fp32 probabilities: a flipped near-tie member moves a cell
         # by <= 1/k of the value spread.  Everything else agrees to 1e-4 relative.
         rel = np.abs(attn[:, num] - ref[:, num]) / np.maximum(np.abs(ref[:, num]), 1e-6)
-        assert (rel > 1e-4).mean() < 0.005, f"{(rel > 1e-4).mean():.4%} of numeric attention cells beyond 1e-4"
-        assert rel.max() < 2e-3, rel.max()
+        # adult: 19 000 valid keys inside a logit range of 0.002 ... 0.03 put about ten keys within 1e-6 of EVERY k-th
+        # logit, and the reference's kept set among them follows its fp32 rounding; test_adult_attention_cells_adjudicated
+        # shows in fp64 that every cell counted here is such a near-tie and that this build's value is the exact one
+        frac_max, rel_max = (0.012, 0.1) if tag == "e2e_adult" else (0.005, 2e-3)
+        assert (rel > 1e-4).mean() < frac_max, f"{(rel > 1e-4).mean():.4%} of numeric attention cells beyond 1e-4"
+        assert rel.max() < rel_max, rel.max()
     mism = (attn[:, ~num] != ref[:, ~num]).mean() if (~num).any() else 0.0
     assert mism < 0.002, f"categorical attention cells differing from the reference: {mism:.4%}"
     scores = z["scores"]
@@ -108,7 +138,11 @@ def test_end_to_end(tmp_path, tag, csv_name):
     # amplified (the reference's own runs at different thread counts are 2e-5 apart after TWO epochs,
     # e2e_hospital_spread.json), so that pin only guards against a gross divergence
     if "valid_rows_differing" in pins:
-        assert pins.pop("valid_rows_differing") <= 40
+        # hospital: measured 28 of 270 entries; torch's own CPU path moves 11 - 13 between 1 and 8 threads.  adult (5 830
+        # rows selected by 1 000 full-table Adam steps through dropout): measured 1 841; torch's own CPU path differs from
+        # ITSELF by 1 685 - 1 781 entries between 1, 2 and 8 threads (tools/valid_index_sensitivity.py adult) -- the
+        # selection is not a reproducible quantity there, the bound only guards against a different procedure
+        assert pins.pop("valid_rows_differing") <= (2500 if tag == "e2e_adult" else 40)
     for nm, d in pins.items():
         tol = 1e-7 if nm.endswith("ep1") else 1e-6 if nm.endswith("ep2") else 5e-4
         assert d < tol, (nm, d)
@@ -122,6 +156,14 @@ def test_end_to_end(tmp_path, tag, csv_name):
         # the returned table is the best pass's: the same bound against the reference's final scores
         assert abs(final[0] - float(z["armse"])) <= 4 * max(sp["armse_std_per_pass"])
         assert abs(final[1] - float(z["amae"])) <= 4 * max(sp["amae_std_per_pass"])
+    elif tag == "e2e_adult":
+        # the reference's own two runs (8 and 4 intra-op threads, tests/golden/e2e_adult_spread.json) are 6e-5 apart in both
+        # scores after 100 epochs; "identical to 3 decimals" is asserted as |difference| <= 5e-4
+        sp = json.load(open(os.path.join(GOLD, "e2e_adult_spread.json")))
+        assert max(abs(a_ - b_) for a_, b_ in zip(sp["runs"][0]["final"], sp["runs"][1]["final"])) < 2e-4
+        for (ep, r, m), (rr, mm) in zip(log, scores):
+            assert abs(r - rr) <= 5e-4 and abs(m - mm) <= 5e-4, (ep, r, rr, m, mm)
+        assert abs(final[0] - float(z["armse"])) <= 5e-4 and abs(final[1] - float(z["amae"])) <= 5e-4
     else:
         # all-numeric table, no arg-max to flip: scores agree far inside 3 decimals
         for (ep, r, m), (rr, mm) in zip(log, scores):
@@ -224,3 +266,80 @@ def test_end_to_end_throughput_mode(tmp_path):
     # the library no longer holds the trainer's stream-offset counter: two plain calls draw the same noise
     x0 = torch.rand(64, 8, device="cuda:0")
     assert torch.equal(ops.forward_noise(x0, 3, 6, seed=1, stream_id=5), ops.forward_noise(x0, 3, 6, seed=1, stream_id=5))
+
+
+def test_adult_attention_cells_adjudicated(tmp_path):
+    """The attention fill of the reference's ``adult`` table at its full size (24 118 rows, k = 1 205, the window
+    selection) against the table the reference itself produced (tests/golden/e2e_adult.npz), cell by cell:
+     * every numeric cell that differs by more than 1e-4 relative, and every categorical cell that differs, is
+       recomputed in fp64 on the device from the same encoded inputs: its k-th and (k+1)-th largest logits are closer
+       than 1e-6 (the north star's tie exemption: which of the tied keys the reference keeps follows the rounding of its
+       fp32 probabilities), and this build's encoded value equals the fp64 closed form to 2e-6;
+     * a sample of the agreeing cells equals the fp64 closed form as well;
+     * no more than 7 % of a column's missing cells differ at all, and at most 0.1 % of the categorical cells."""
+    from ddgani_amd import ops
+    from ddgani_amd.BaseLine import Mean
+    from ddgani_amd.utils import util
+    from ddgani_amd.utils.data_loader import data_loader, set_label, value_loader
+    dev = torch.device("cuda:0")
+    z = load("e2e_adult")
+    param = json.loads(str(z["param_json"]))
+    path = str(tmp_path) + "/"
+    label_file, _ = set_label(os.path.join(GOLD, "adult.csv"), path, "True")
+    miss_rate, seed = float(z["miss_rate"]), int(z["seed"])
+    np.random.seed(0); random.seed(0); torch.manual_seed(0)
+    (_, miss_data, data_m, _, _, _, con, nan_data, _, all_data) = data_loader(
+        label_file, miss_rate, param["categorical_cols"], "True", "MCAR", seed)
+    values, _, value_cat = value_loader(label_file, con, "True")
+    _, enc = util.categorical_to_code(all_data, value_cat, enc=None)
+    dm = np.asarray(data_m)
+    assert np.array_equal(dm, z["data_m"])
+    aid = pd.DataFrame(Mean.fill_data_mean(nan_data, con), columns=values)
+    corr = z["corr"]
+    df, code = util.init_attn_2(corr, aid.copy(), data_m, param["categorical_cols"], enc, value_cat, dev, param["top_k"])
+    a = df.copy()                                     # (a copy: reconvert_data ordinal-encodes the frame it is given)
+    a[value_cat] = enc.transform(a[value_cat])
+    mine, ref = a.values.astype(float), z["attn_coded"]
+    # the encoded inputs of that call, for the fp64 closed form
+    fields, X, M, W, widths = util.attention_inputs(corr, aid, data_m, param["categorical_cols"], enc, value_cat, device=dev)
+    lay = ops.FieldLayout(widths, dev)
+    off = lay.offsets
+    N = X.shape[0]
+    k = util.topk_count(N, param["top_k"])
+    assert (N, k, lay.D) == (24118, 1205, 118)
+    X64, W64 = (X * M).double(), W.double()
+    m8 = torch.tensor(dm != 0, dtype=torch.uint8, device=dev)
+
+    def closed_form(j, c):
+        kk = torch.nonzero(m8[:, c] == 1).flatten()
+        kk = kk[kk != j]
+        s_ = X64[kk] @ (W64[c] * X64[j])
+        top = torch.topk(s_, k + 1).values
+        keep = s_ >= top[k - 1]
+        w = torch.exp(s_ - s_.max())
+        xv = X64[kk][:, off[c]:off[c + 1]]
+        return float(top[k - 1] - top[k]), (w[keep, None] * xv[keep]).sum(0) / w[keep].sum()
+
+    rng = np.random.default_rng(5)
+    n_adj = 0
+    for c in range(len(values)):
+        miss = dm[:, c] == 0
+        if c in con:
+            rel = np.abs(mine[:, c] - ref[:, c]) / np.maximum(np.abs(ref[:, c]), 1e-6)
+            bad = np.where((rel > 1e-4) & miss)[0]
+            assert len(bad) <= 0.07 * miss.sum(), (values[c], len(bad), int(miss.sum()))
+        else:
+            bad = np.where((mine[:, c] != ref[:, c]) & miss)[0]
+            assert len(bad) <= 1e-3 * miss.sum() + 1, (values[c], len(bad))
+        assert np.array_equal(mine[~miss, c], ref[~miss, c])              # observed cells untouched
+        good = rng.choice(np.setdiff1d(np.where(miss)[0], bad), 3, replace=False)
+        for j in bad:
+            gap, fill = closed_form(int(j), c)
+            assert gap <= 1e-6, (values[c], int(j), gap, mine[j, c], ref[j, c])
+            assert float((code[j, off[c]:off[c + 1]].double() - fill).abs().max()) <= 2e-6, (values[c], int(j))
+            n_adj += 1
+        for j in good:
+            _, fill = closed_form(int(j), c)
+            assert float((code[j, off[c]:off[c + 1]].double() - fill).abs().max()) <= 2e-6, (values[c], int(j))
+    print("cells adjudicated in fp64:", n_adj)
+    assert n_adj > 0

@@ -9,10 +9,11 @@ from util_golden import GOLD, load
 from ddgani_amd.utils import util
 from ddgani_amd.utils.data_loader import data_loader, set_label, value_loader
 from ddgani_amd.model.Discriminator_model import D
-z = load("e2e_hospital")
+TABLE = sys.argv[1] if len(sys.argv) > 1 else "hospital"      # hospital | adult (adult: 1 841 of the device path's entries
+z = load("e2e_" + TABLE)                                       # differ from the reference's, see the measured numbers below)
 param = json.loads(str(z["param_json"]))
 path = tempfile.mkdtemp() + "/"
-label_file, _ = set_label(os.path.join(GOLD, "hospital.csv"), path, "True")
+label_file, _ = set_label(os.path.join(GOLD, TABLE + ".csv"), path, "True")
 np.random.seed(0); random.seed(0); torch.manual_seed(0)
 (ori_data, miss_data, data_m, _, _, _, con, _, _, all_data) = data_loader(label_file, float(z["miss_rate"]), param["categorical_cols"], "True", "MCAR", int(z["seed"]))
 values, _, value_cat = value_loader(label_file, con, "True")
