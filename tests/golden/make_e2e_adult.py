@@ -8,7 +8,8 @@ Stored (plain arrays): data_m, the column-association map, the attention-filled 
 ARMSE / AMAE per sampling pass and of its returned table, its validation split, weights after epochs 1 / 2 / 10.
 adult.csv (one of the reference's data files = fixture data) is copied next to it.
 
-    python tests/golden/make_e2e_adult.py [epochs=100]
+    python tests/golden/make_e2e_adult.py [epochs=100] [table=adult] [miss_type=MCAR]
+    python tests/golden/make_e2e_adult.py 100 spam MNAR      # BASELINE configs[1]: a numeric UCI table under MNAR (e2e_spam_MNAR.npz)
     DDG_REF_THREADS=1 DDG_SCORES_ONLY=1 python tests/golden/make_e2e_adult.py     # scores only (self-spread of the reference)
 """
 import json
@@ -29,7 +30,7 @@ sys.path.insert(0, HERE)
 import make_e2e as m                                          # noqa: E402  (sys.path, torchmetrics stub, reference imports)
 
 
-def main(epochs=100, name="adult", miss_rate=0.2, seed=42):
+def main(epochs=100, name="adult", miss_type="MCAR", miss_rate=0.2, seed=42):
     threads = int(os.environ.get("DDG_REF_THREADS", "0"))
     if threads:
         torch.set_num_threads(threads)
@@ -74,7 +75,7 @@ def main(epochs=100, name="adult", miss_rate=0.2, seed=42):
     t0 = time.time()
     np.random.seed(0); random.seed(0); torch.manual_seed(0)
     (ori_data, miss_data, data_m, label_data, true_data, true_label, continuous_cols, nan_data, test_data,
-     all_data) = m.data_loader(label_file, miss_rate, param["categorical_cols"], "True", "MCAR", seed)
+     all_data) = m.data_loader(label_file, miss_rate, param["categorical_cols"], "True", miss_type, seed)
     values, value_num, value_cat = m.value_loader(label_file, continuous_cols, "True")
     miss_data.columns = values
     miss_data.to_csv(path + f"miss_data_{miss_rate}.csv", index=None)
@@ -97,7 +98,8 @@ def main(epochs=100, name="adult", miss_rate=0.2, seed=42):
     if value_cat:
         a[value_cat] = enc.transform(a[value_cat])
     shutil.copy(src_csv, os.path.join(HERE, name + ".csv"))
-    np.savez_compressed(os.path.join(HERE, f"e2e_{name}.npz"), miss_type=np.array("MCAR"), scores=np.array(log),
+    tag = name if miss_type == "MCAR" else f"{name}_{miss_type}"
+    np.savez_compressed(os.path.join(HERE, f"e2e_{tag}.npz"), miss_type=np.array(miss_type), scores=np.array(log),
                         armse=np.array(armse), amae=np.array(amae), data_m=np.asarray(data_m).astype(np.int8), corr=corr,
                         attn_coded=a.values.astype(float), epochs=np.array(epochs),
                         categorical_cols=np.array(param["categorical_cols"], dtype=np.int64), T=np.array(param["T"]),
@@ -107,4 +109,5 @@ def main(epochs=100, name="adult", miss_rate=0.2, seed=42):
 
 
 if __name__ == "__main__":
-    main(epochs=int(sys.argv[1]) if len(sys.argv) > 1 else 100)
+    main(epochs=int(sys.argv[1]) if len(sys.argv) > 1 else 100, name=sys.argv[2] if len(sys.argv) > 2 else "adult",
+         miss_type=sys.argv[3] if len(sys.argv) > 3 else "MCAR")

@@ -79,7 +79,8 @@ def _run_pipeline(tmp_path, tag, csv_name, rng="host", epochs=None, attn_from_re
             df, code = orig_attn(*a, **k)
             own_attn.append(df.copy())
             ref = pd.DataFrame(z["attn_coded"], columns=values)
-            ref[value_cat] = enc.inverse_transform(ref[value_cat])
+            if value_cat:
+                ref[value_cat] = enc.inverse_transform(ref[value_cat])
             for c in values:
                 if c not in value_cat:
                     ref[c] = ref[c].astype(df[c].dtype)
@@ -101,17 +102,19 @@ def _run_pipeline(tmp_path, tag, csv_name, rng="host", epochs=None, attn_from_re
 
 
 @pytest.mark.parametrize("tag,csv_name", [("e2e_hospital", "hospital.csv"), ("e2e_wine_MNAR", "wine.csv"),
-                                          ("e2e_adult", "adult.csv")])
+                                          ("e2e_adult", "adult.csv"), ("e2e_spam_MNAR", "spam.csv")])
 def test_end_to_end(tmp_path, tag, csv_name):
     """hospital: 9 columns, 7 categorical (one-hot heavy), MCAR 0.2, fallback validation split;
     wine: 13 numeric columns, MNAR (BASELINE.json config 2 style), 142 rows;
+    spam: BASELINE.json configs[1] on the largest numeric UCI table of the reference -- 3 680 rows x 57 numeric columns, MNAR,
+    k = 184 (tests/golden/make_e2e_adult.py 100 spam MNAR);
     adult: BASELINE.json configs[0] at its full size -- 24 118 rows after the train split, 14 columns (8 categorical,
     D = 118), MCAR 0.2, top_k 0.05 (k = 1 205: the window selection on a real table), Learner on the income label, FD
     plug-in on education / education-num, fallback validation split (tests/golden/make_e2e_adult.py).  About 1 % of
     adult's attention-filled numeric cells are near-ties on which the reference's fp32 rounding decides (adjudicated in
-    test_adult_attention_cells_adjudicated), so its diffusion stage is run on the reference's attention table: the
+    test_attention_cells_adjudicated), so its diffusion stage is run on the reference's attention table: the
     trajectory pins and scores then compare the training / sampling arithmetic on identical inputs."""
-    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, tag, csv_name, attn_from_reference=tag == "e2e_adult")
+    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, tag, csv_name, attn_from_reference=tag in ("e2e_adult", "e2e_spam_MNAR"))
     assert np.array_equal(np.asarray(data_m), z["data_m"])
     # attention fill: numeric cells to 1e-4 relative; categorical cells (arg-max of a softmax-weighted
     # vote) may flip only on near-ties
@@ -121,11 +124,14 @@ def test_end_to_end(tmp_path, tag, csv_name):
         # near-tie slack: this table is one-hot heavy, kept sets hold hundreds of tied
         # logits, and the reference thresholds fp32 probabilities: a flipped near-tie member moves a cell
         # by <= 1/k of the value spread.  Everything else agrees to 1e-4 relative.
-        rel = np.abs(attn[:, num] - ref[:, num]) / np.maximum(np.abs(ref[:, num]), 1e-6)
+        # (spam: word frequencies, most cells 0 and fills of the order 1e-8: relative to the larger of |value| and the
+        # column's standard deviation there, a relative error of a value that is zero means nothing)
+        floor = ref[:, num].std(0, keepdims=True) if tag == "e2e_spam_MNAR" else 1e-6
+        rel = np.abs(attn[:, num] - ref[:, num]) / np.maximum(np.abs(ref[:, num]), floor)
         # adult: 19 000 valid keys inside a logit range of 0.002 ... 0.03 put about ten keys within 1e-6 of EVERY k-th
-        # logit, and the reference's kept set among them follows its fp32 rounding; test_adult_attention_cells_adjudicated
+        # logit, and the reference's kept set among them follows its fp32 rounding; test_attention_cells_adjudicated
         # shows in fp64 that every cell counted here is such a near-tie and that this build's value is the exact one
-        frac_max, rel_max = (0.012, 0.1) if tag == "e2e_adult" else (0.005, 2e-3)
+        frac_max, rel_max = (0.012, 0.1) if tag == "e2e_adult" else (0.012, 0.5) if tag == "e2e_spam_MNAR" else (0.005, 2e-3)
         assert (rel > 1e-4).mean() < frac_max, f"{(rel > 1e-4).mean():.4%} of numeric attention cells beyond 1e-4"
         assert rel.max() < rel_max, rel.max()
     mism = (attn[:, ~num] != ref[:, ~num]).mean() if (~num).any() else 0.0
@@ -142,7 +148,8 @@ def test_end_to_end(tmp_path, tag, csv_name):
         # rows selected by 1 000 full-table Adam steps through dropout): measured 1 841; torch's own CPU path differs from
         # ITSELF by 1 685 - 1 781 entries between 1, 2 and 8 threads (tools/valid_index_sensitivity.py adult) -- the
         # selection is not a reproducible quantity there, the bound only guards against a different procedure
-        assert pins.pop("valid_rows_differing") <= (2500 if tag == "e2e_adult" else 40)
+        # spam (736 rows selected): measured 94; torch against itself 46 - 48
+        assert pins.pop("valid_rows_differing") <= {"e2e_adult": 2500, "e2e_spam_MNAR": 150}.get(tag, 40)
     for nm, d in pins.items():
         tol = 1e-7 if nm.endswith("ep1") else 1e-6 if nm.endswith("ep2") else 5e-4
         assert d < tol, (nm, d)
@@ -268,28 +275,31 @@ def test_end_to_end_throughput_mode(tmp_path):
     assert torch.equal(ops.forward_noise(x0, 3, 6, seed=1, stream_id=5), ops.forward_noise(x0, 3, 6, seed=1, stream_id=5))
 
 
-def test_adult_attention_cells_adjudicated(tmp_path):
+@pytest.mark.parametrize("tag,csv_name,shape,col_frac", [("e2e_adult", "adult.csv", (24118, 1205, 118), 0.07),
+                                                         ("e2e_spam_MNAR", "spam.csv", (3680, 184, 57), 0.25)])
+def test_attention_cells_adjudicated(tmp_path, tag, csv_name, shape, col_frac):
     """The attention fill of the reference's ``adult`` table at its full size (24 118 rows, k = 1 205, the window
-    selection) against the table the reference itself produced (tests/golden/e2e_adult.npz), cell by cell:
+    selection) and of its ``spam`` table under MNAR (3 680 rows, 57 sparse numeric columns, k = 184, the radix path)
+    against the tables the reference itself produced (tests/golden/e2e_adult.npz, e2e_spam_MNAR.npz), cell by cell:
      * every numeric cell that differs by more than 1e-4 relative, and every categorical cell that differs, is
        recomputed in fp64 on the device from the same encoded inputs: its k-th and (k+1)-th largest logits are closer
        than 1e-6 (the north star's tie exemption: which of the tied keys the reference keeps follows the rounding of its
        fp32 probabilities), and this build's encoded value equals the fp64 closed form to 2e-6;
      * a sample of the agreeing cells equals the fp64 closed form as well;
-     * no more than 7 % of a column's missing cells differ at all, and at most 0.1 % of the categorical cells."""
+     * no more than ``col_frac`` of a column's missing cells differ at all, and at most 0.1 % of the categorical cells."""
     from ddgani_amd import ops
     from ddgani_amd.BaseLine import Mean
     from ddgani_amd.utils import util
     from ddgani_amd.utils.data_loader import data_loader, set_label, value_loader
     dev = torch.device("cuda:0")
-    z = load("e2e_adult")
+    z = load(tag)
     param = json.loads(str(z["param_json"]))
     path = str(tmp_path) + "/"
-    label_file, _ = set_label(os.path.join(GOLD, "adult.csv"), path, "True")
+    label_file, _ = set_label(os.path.join(GOLD, csv_name), path, "True")
     miss_rate, seed = float(z["miss_rate"]), int(z["seed"])
     np.random.seed(0); random.seed(0); torch.manual_seed(0)
     (_, miss_data, data_m, _, _, _, con, nan_data, _, all_data) = data_loader(
-        label_file, miss_rate, param["categorical_cols"], "True", "MCAR", seed)
+        label_file, miss_rate, param["categorical_cols"], "True", str(z["miss_type"]), seed)
     values, _, value_cat = value_loader(label_file, con, "True")
     _, enc = util.categorical_to_code(all_data, value_cat, enc=None)
     dm = np.asarray(data_m)
@@ -298,7 +308,8 @@ def test_adult_attention_cells_adjudicated(tmp_path):
     corr = z["corr"]
     df, code = util.init_attn_2(corr, aid.copy(), data_m, param["categorical_cols"], enc, value_cat, dev, param["top_k"])
     a = df.copy()                                     # (a copy: reconvert_data ordinal-encodes the frame it is given)
-    a[value_cat] = enc.transform(a[value_cat])
+    if value_cat:
+        a[value_cat] = enc.transform(a[value_cat])
     mine, ref = a.values.astype(float), z["attn_coded"]
     # the encoded inputs of that call, for the fp64 closed form
     fields, X, M, W, widths = util.attention_inputs(corr, aid, data_m, param["categorical_cols"], enc, value_cat, device=dev)
@@ -306,7 +317,7 @@ def test_adult_attention_cells_adjudicated(tmp_path):
     off = lay.offsets
     N = X.shape[0]
     k = util.topk_count(N, param["top_k"])
-    assert (N, k, lay.D) == (24118, 1205, 118)
+    assert (N, k, lay.D) == shape
     X64, W64 = (X * M).double(), W.double()
     m8 = torch.tensor(dm != 0, dtype=torch.uint8, device=dev)
 
@@ -314,7 +325,10 @@ def test_adult_attention_cells_adjudicated(tmp_path):
         kk = torch.nonzero(m8[:, c] == 1).flatten()
         kk = kk[kk != j]
         s_ = X64[kk] @ (W64[c] * X64[j])
-        top = torch.topk(s_, k + 1).values
+        if s_.numel() <= k:                                   # fewer valid keys than k: all are kept, no k-th gap
+            top = torch.cat([torch.sort(s_, descending=True).values, s_.new_full((k + 1 - s_.numel(),), -1e30)])
+        else:
+            top = torch.topk(s_, k + 1).values
         keep = s_ >= top[k - 1]
         w = torch.exp(s_ - s_.max())
         xv = X64[kk][:, off[c]:off[c + 1]]
@@ -325,14 +339,16 @@ def test_adult_attention_cells_adjudicated(tmp_path):
     for c in range(len(values)):
         miss = dm[:, c] == 0
         if c in con:
-            rel = np.abs(mine[:, c] - ref[:, c]) / np.maximum(np.abs(ref[:, c]), 1e-6)
+            floor = ref[:, c].std() if tag == "e2e_spam_MNAR" else 1e-6      # (see test_end_to_end)
+            rel = np.abs(mine[:, c] - ref[:, c]) / np.maximum(np.abs(ref[:, c]), floor)
             bad = np.where((rel > 1e-4) & miss)[0]
-            assert len(bad) <= 0.07 * miss.sum(), (values[c], len(bad), int(miss.sum()))
+            assert len(bad) <= col_frac * miss.sum() + 1, (values[c], len(bad), int(miss.sum()))
         else:
             bad = np.where((mine[:, c] != ref[:, c]) & miss)[0]
             assert len(bad) <= 1e-3 * miss.sum() + 1, (values[c], len(bad))
         assert np.array_equal(mine[~miss, c], ref[~miss, c])              # observed cells untouched
-        good = rng.choice(np.setdiff1d(np.where(miss)[0], bad), 3, replace=False)
+        cand = np.setdiff1d(np.where(miss)[0], bad)
+        good = rng.choice(cand, min(3, len(cand)), replace=False)
         for j in bad:
             gap, fill = closed_form(int(j), c)
             assert gap <= 1e-6, (values[c], int(j), gap, mine[j, c], ref[j, c])

@@ -10,16 +10,17 @@ from ddgani_amd.utils import util
 from ddgani_amd.utils.data_loader import data_loader, set_label, value_loader
 from ddgani_amd.model.Discriminator_model import D
 TABLE = sys.argv[1] if len(sys.argv) > 1 else "hospital"      # hospital | adult (adult: 1 841 of the device path's entries
-z = load("e2e_" + TABLE)                                       # differ from the reference's, see the measured numbers below)
+z = load("e2e_" + TABLE)                                       # (also: spam_MNAR)                                       # differ from the reference's, see the measured numbers below)
 param = json.loads(str(z["param_json"]))
 path = tempfile.mkdtemp() + "/"
-label_file, _ = set_label(os.path.join(GOLD, TABLE + ".csv"), path, "True")
+label_file, _ = set_label(os.path.join(GOLD, TABLE.split("_")[0] + ".csv"), path, "True")
 np.random.seed(0); random.seed(0); torch.manual_seed(0)
-(ori_data, miss_data, data_m, _, _, _, con, _, _, all_data) = data_loader(label_file, float(z["miss_rate"]), param["categorical_cols"], "True", "MCAR", int(z["seed"]))
+(ori_data, miss_data, data_m, _, _, _, con, _, _, all_data) = data_loader(label_file, float(z["miss_rate"]), param["categorical_cols"], "True", str(z["miss_type"]) if "miss_type" in z.files else "MCAR", int(z["seed"]))
 values, _, value_cat = value_loader(label_file, con, "True")
 _, enc = util.categorical_to_code(all_data, value_cat, enc=None)
 attn = pd.DataFrame(z["attn_coded"], columns=values)
-attn[value_cat] = enc.inverse_transform(attn[value_cat])
+if value_cat:
+    attn[value_cat] = enc.inverse_transform(attn[value_cat])
 coded, _ = util.categorical_to_code(attn.copy(), value_cat, enc)
 coded.columns = list(range(coded.shape[1]))
 fields, feed = util.Data_convert(coded, param["model_name"], con)
