@@ -261,12 +261,15 @@ def test_imputation_path_on_reference_weights(tmp_path):
         assert round(score[0], 3) == round(float(rr), 3) or abs(score[0] - rr) < 1e-5
 
 
-def test_end_to_end_throughput_mode(tmp_path):
+@pytest.mark.parametrize("tag,csv_name", [("e2e_hospital", "hospital.csv"), ("e2e_adult", "adult.csv")])
+def test_end_to_end_throughput_mode(tmp_path, tag, csv_name):
     """The same pipeline with on-chip random numbers and the training steps replayed as HIP graphs (rng="chip": what
-    a production run uses).  Not a replay of the reference's streams, so the scores are compared statistically: after
-    100 epochs within 0.02 of the reference's ARMSE / AMAE on this run (its own thread-count spread is 0.003)."""
-    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, "e2e_hospital", "hospital.csv", rng="chip", epochs=100)
+    a production run uses), on hospital and on adult at its full size (device encode / decode, window selection, fallback
+    discriminator on the device).  Not a replay of the reference's streams, so the scores are compared statistically:
+    after 100 epochs within 0.02 of the reference's ARMSE / AMAE on this run (its own thread-count spread is 0.003)."""
+    z, data_m, attn, log, final, con, pins = _run_pipeline(tmp_path, tag, csv_name, rng="chip", epochs=100)
     assert len(log) == 1 and log[0][0] == 100
+    print("throughput mode", tag, log, "reference", z["scores"].tolist())
     assert abs(log[0][1] - float(z["scores"][0][0])) < 0.02, log
     assert abs(log[0][2] - float(z["scores"][0][1])) < 0.02, log
     from ddgani_amd import ops
