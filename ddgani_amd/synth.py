@@ -18,6 +18,9 @@ WORKLOADS = {
                desc="synthetic 1M rows x 64 mixed cols (every 4th categorical, cardinality 8), MAR, top_k=10"),
     "c4": dict(rows=10_000_000, cols=128, cat_every=0, card=0, miss="MCAR", rate=0.5, k=10, T=6,
                desc="synthetic 10M rows x 128 numeric cols, MCAR 0.5, top_k=10"),
+    # c5 is all numeric: the hot path (fill + sampler) is what it measures.  The FD plug-in of BASELINE's configs[4]
+    # discovers nothing on such a table (model/FD_model.py:208-210 skips a numeric right-hand side, as the reference does);
+    # it is exercised on mixed tables instead: hospital, adult, and 200 000 synthetic rows (tests/test_gpu_fd.py).
     "c5": dict(rows=2_000_000, cols=256, cat_every=0, card=0, miss="Region", rate=0.2, k=10, T=6,
                desc="synthetic 2M rows x 256 numeric cols, Region missingness, top_k=10"),
 }
