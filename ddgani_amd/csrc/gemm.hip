@@ -848,6 +848,7 @@ static int linear_impl(const float *A, const float *A2, int in1, const float *W,
     if (wsplit && rows >= SPLIT_MIN_ROWS && !A2 && (in & 3) == 0 && !linear_force_f32()) {
         const int64_t n = (int64_t)out * in;
         k_split_weights<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, wsplit, out, in);
+        DDG_CHECK_LAUNCH();
         p.Ws = wsplit;
     }
     return launch_linear(p, prologue, (hipStream_t)stream);
@@ -944,16 +945,27 @@ extern "C" int ddg_denoiser_fwd(const ddg_gen_weights *w, const float *x_t, cons
 // vectors live in a file-scope device array of DDG_STATIC_SCRATCH_BYTES; every GPU holds its own copy
 // at its own address until the process ends.  The array's name is only a host-side handle:
 // its device address is looked up once per device with hipGetSymbolAddress and that pointer is what
-// the kernels and hipMemsetAsync receive.  Calls that overlap on one GPU share the array and race.
+// the kernels receive.  The array belongs to the CURRENT device, so the caller's tensors and stream must live on it: the
+// entry point checks that x_t and out do (hipPointerGetAttributes) and refuses otherwise -- a symbol address of one GPU
+// is not valid on another.  Calls that overlap on one GPU share the array and race.
 // ---------------------------------------------------------------------------------------------
 static __device__ __align__(256) unsigned char scratch[DDG_STATIC_SCRATCH_BYTES];
 #define DDG_MAX_DEVICES 64
 static void *g_scratch_ptr[DDG_MAX_DEVICES];
 static std::mutex g_scratch_mu;
 
-static int static_scratch(void **out) {
+static int static_scratch(void **out, const void *p0, const void *p1) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DDG_MAX_DEVICES) return DDG_E_LAUNCH;
+    for (const void *p : {p0, p1}) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); continue; }      // not a tracked pointer: nothing to compare
+        if (at.type == hipMemoryTypeDevice && at.device != dev) {
+            fprintf(stderr, "ddgani: ddg_denoiser_fwd_static: a tensor lives on device %d, the current device is %d "
+                            "(the static scratch belongs to the current device)\n", at.device, dev);
+            return DDG_E_ARG;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         void *ptr = nullptr;
@@ -983,9 +995,9 @@ extern "C" int ddg_denoiser_fwd_static(const ddg_gen_weights *w, const float *x_
         return DDG_E_SCRATCH_LIMIT;
     }
     void *ptr = nullptr;
-    int rc = static_scratch(&ptr);
+    int rc = static_scratch(&ptr, x_t, out);
     if (rc) return rc;
-    // the BatchNorm sums must start at zero: ddg_denoiser_fwd clears them (hipMemsetAsync on `ptr`) on every call;
+    // the BatchNorm sums must start at zero: ddg_denoiser_fwd clears them (a kernel on `ptr`, zero_async) on every call;
     // everything else in the array is written before it is read
     return ddg_denoiser_fwd(w, x_t, t, t_uniform, drop0, drop1, drop2, drop_p, seed, stream_id, bn_eps, offsets, is_cat,
                             C, apply_head, out, rows, ptr, (size_t)DDG_STATIC_SCRATCH_BYTES, stream);

@@ -25,7 +25,8 @@ def test_static_scratch_entry_point_matches_workspace_entry_point():
     lay = ops.FieldLayout(widths, dev)
     P = ops.GenParams(synth.random_generator_state(lay.D, 6), dev)
     # the array keeps the last call's contents: poison check = a large call first, then a smaller one
-    for rows, seed in ((3000, 1), (777, 2), (128, 3)):
+    # (9 000 rows: the branch of 8 192 rows and more -- split-f16 layer kernels, weights pre-split INTO the static array)
+    for rows, seed in ((9000, 5), (3000, 1), (777, 2), (128, 3)):
         x_t, t, drops = _case(rows, lay, P, dev, seed)
         for tt in (t, 4):
             want = ops.denoiser_fwd(P, x_t, tt, lay, drops=drops)
