@@ -10,10 +10,11 @@
 // (all others are -inf in the reference); the query's own row is never among those keys.
 //
 // Data layout in HBM (workspace):
-//   Xkp [Nk][DP]   key rows, zero padded to DP = 8*KS4 columns (16-byte aligned rows)
-//   Xqp [Nq][DP]   query rows (aliases Xkp when queries and keys are the same array)
+//   Xkp [Nk][DP]   key rows, zero padded to DP = 8*KS4 columns (16-byte aligned rows); in table order, except on the
+//                  screening path (k <= DDG_MAX_TOPK_REG, filter mode): there in descending-norm order (k_bucket_count)
+//   Xqp [Nq][DP]   query rows, table order (aliases Xkp when queries and keys are the same array and Xkp is in table order)
 //   Wp  [C][DP]    column weights
-//   klist [C][Nk]  ascending indices of the keys observed in column c (nk[c] of them)
+//   klist [C][Nk]  ascending positions in Xkp of the keys observed in column c (nk[c] of them)
 //   qlist [QB*128] per column, ascending local indices of the rows MISSING column c, each
 //                  column padded with -1 to a multiple of 128 (one block = 128 queries of ONE column)
 //   tau / smax / prefix / rank  [QB*128]  per-query selection state

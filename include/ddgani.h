@@ -354,7 +354,10 @@ int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q_row_offset
 
 /* The three phases of ddg_attn_topk_fill, separately callable on the same workspace (same
  * reference lines; used to time the phases and, multi-GPU, to prepare once per all-gather):
- *   prepare: padded operands + per-column key / query index lists      (utils/util.py:439-448)
+ *   prepare: padded operands + per-column key / query index lists      (utils/util.py:439-448);
+ *            on the screening path (filter mode, k <= DDG_MAX_TOPK_REG) the padded key rows are stored in
+ *            descending order of their 2-norm: which keys a query keeps does not depend on the order,
+ *            how many candidates reach the exact pass does (DDG_KEY_ORDER=row: table order)
  *   select : out_code <- Xq0, then ONE similarity pass                 (utils/util.py:452-466)
  *            k <= DDG_MAX_TOPK_REG: the k+2 largest logits and their key rows are kept in
  *            registers; every pair whose k-th and (k+1)-th logits differ, or tie while the
