@@ -1947,7 +1947,7 @@ __global__ void k_keys_screen(const float *__restrict__ Xkp, int64_t rows, int D
         s2 = wave_sum(s2);
         best = fmaxf(best, sqrtf(s2) * 1.000001f);
     }
-    if (lane == 0) atomicMax(kmax_bits, __float_as_uint(best));     // non-negative floats order like their bits
+    if (lane == 0 && kmax_bits) atomicMax(kmax_bits, __float_as_uint(best));     // non-negative floats order like their bits
 }
 
 // largest |element| of the padded keys (non-negative floats order like their bits)
@@ -2640,7 +2640,10 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
     if (qpb == QPBF)
     {
         k_maxabs<<<egrid(Nk * DP), 256, 0, s>>>(w.Xkp, Nk * DP, reinterpret_cast<unsigned *>(w.flags + 2));
-        k_keys_screen<<<egrid(Nk * 64), 256, 0, s>>>(w.Xkp, Nk, DP, w.Xkh, reinterpret_cast<unsigned *>(w.flags + 1),
+        // (norm-ordered keys: the largest norm is k_row_norms' and must stay EXACTLY the value the buckets were cut with --
+        // the screening kernel recomputes a key's bucket from it; a last-bit difference from another summation order
+        // could move a key at a bucket's edge and make the per-chunk bound one bucket too small)
+        k_keys_screen<<<egrid(Nk * 64), 256, 0, s>>>(w.Xkp, Nk, DP, w.Xkh, perm ? nullptr : reinterpret_cast<unsigned *>(w.flags + 1),
                                                      reinterpret_cast<const unsigned *>(w.flags + 2),
                                                      reinterpret_cast<float *>(w.flags + 3));
     }
