@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the "
                                                      "multi-rank path on a one-GPU box together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--even-shards", action="store_true", help="attention queries sharded by even row counts instead of equal "
+                                                               "work (A/B: Region missingness leaves most ranks idle)")
     ap.add_argument("--cpu-rows", type=int, default=8192, help="sample rows for the CPU attention-fill timing")
     return ap.parse_args()
 
@@ -204,11 +206,18 @@ def main():
     if a.topk > 0:
         k = int(a.topk) if a.topk >= 1 else max(1, int(N * a.topk))
     comm = ddist.Comm()
-    lo, hi = ddist.shard_bounds(N, comm.world)[comm.rank]
-    Xq = tab.X_attn[lo:hi].contiguous()
+    # two row partitions: the attention fill's queries by equal WORK (missing cells x observed keys: Region missingness
+    # puts every pair into a block of rows), the sampler's rows by the fixed virtual shards (cost per row)
+    abounds = ([(0, N)] if not comm.on else ddist.shard_bounds(N, comm.world) if a.even_shards else
+               ddist.work_balanced_bounds(tab.m8, comm.world))
+    lo, hi = abounds[comm.rank]
+    slo, shi = ddist.shard_bounds(N, comm.world)[comm.rank]
+    Xq = tab.X_attn[lo:hi].contiguous()                   # (one GPU: the whole table; else taken from the gathered keys)
     mq = tab.m8[lo:hi].contiguous()
-    xd = tab.x_diff[lo:hi].contiguous()
-    Md = tab.M[lo:hi].contiguous()
+    Xk_local = tab.X_attn[slo:shi].contiguous()           # this rank's contribution to the key all-gather: even shards
+    mk_local = tab.m8[slo:shi].contiguous()
+    xd = tab.x_diff[slo:shi].contiguous()
+    Md = tab.M[slo:shi].contiguous()
     # algorithmic work of the similarity: (query pair, key) units, 2*D flop each
     nobs = tab.m8.sum(0).double()                         # observed keys per column
     nmiss_local = (hi - lo) - mq.sum(0).double()
@@ -230,9 +239,9 @@ def main():
         e[0].record()
         if comm.on:
             counts = [b - a_ for a_, b in ddist.shard_bounds(N, comm.world)]
-            Xk = comm.all_gather_rows(Xq, counts)
-            mk = comm.all_gather_rows(mq, counts)
-            plan = ops.AttnPlan(Xq, mq, Xk, mk, tab.W, lay, k, q_row_offset=lo, mode=amode)
+            Xk = comm.all_gather_rows(Xk_local, counts)
+            mk = comm.all_gather_rows(mk_local, counts)
+            plan = ops.AttnPlan(Xk[lo:hi], mk[lo:hi], Xk, mk, tab.W, lay, k, q_row_offset=lo, mode=amode)
         else:
             plan = ops.AttnPlan(Xq, mq, Xq, mq, tab.W, lay, k, mode=amode)
         plan.prepare()
@@ -276,6 +285,11 @@ def main():
         one = torch.ones(1, dtype=torch.int64, device=cdev)
         dist.all_reduce(one, op=dist.ReduceOp.SUM)         # ranks that actually ran the timed loop
         ranks_seen = int(one.item())
+        wmax = torch.tensor([pairs_local], dtype=torch.float64, device=cdev)
+        wsum = wmax.clone()
+        dist.all_reduce(wmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(wsum, op=dist.ReduceOp.SUM)
+        imbalance = float(wmax.item()) * world / max(float(wsum.item()), 1.0)    # largest share of the similarity work / mean share
         if ranks_seen != a.gpus:
             print(f"bench.py: {ranks_seen} ranks took part, --gpus {a.gpus}", file=sys.stderr)
             sys.exit(3)
@@ -310,7 +324,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {wl['desc']}" + (f" [rows overridden to {N}]" if a.rows else ""),
                        "rows": N, "cols": lay.C, "encoded_dim": lay.D, "top_k": k, "T": T,
-                       "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU"},
+                       "parallelism": (f"rows sharded x{world} (attention queries by " + ("even row counts" if a.even_shards else "equal work")
+                                       + f"; largest / mean share of the similarity work {imbalance:.3f})") if world > 1 else "single GPU"},
             "phases_ms": {"prepare(+allgather)": sum(prep_ms) / len(prep_ms), "select": sel,
                           "fill": sum(fill_ms) / len(fill_ms), "sampler+merge": sum(samp_ms) / len(samp_ms)},
             "roofline": {"bound": "mfma",

@@ -2597,6 +2597,7 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
                                 const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
                                 int64_t Nk, int C, int D, int64_t k, int mode, void *workspace,
                                 size_t workspace_bytes, void *stream) {
+    if (Nq == 0 && Nk >= 0 && C >= 1 && k >= 1) return DDG_OK;       // an empty query shard (its pointers may be NULL)
     if (!Xq0 || !mq || !Xk0 || !mk || !W || !offsets_host || k < 1) return DDG_E_ARG;
     int rc = attn_check_dims(Nq, Nk, C, D, mode);
     if (rc) return rc;
@@ -2690,6 +2691,7 @@ extern "C" int ddg_attn_prepare(const float *Xq0, const uint8_t *mq, int64_t q_r
 extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, int D, int64_t k, int mode,
                                int queries_alias_keys, float *out_code, void *workspace, size_t workspace_bytes,
                                void *stream) {
+    if (Nq == 0 && Nk >= 0 && C >= 1 && k >= 1) return DDG_OK;       // an empty query shard (its pointers may be NULL)
     if (!Xq0 || !out_code) return DDG_E_ARG;
     int rc = attn_check_dims(Nq, Nk, C, D, mode);
     if (rc) return rc;
@@ -2718,6 +2720,7 @@ extern "C" int ddg_attn_select(const float *Xq0, int64_t Nq, int64_t Nk, int C, 
 extern "C" int ddg_attn_fill(const int32_t *offsets_host, int64_t Nq, int64_t Nk, int C, int D, int64_t k, int mode,
                              int queries_alias_keys, float *out_code, float *out_tau, int32_t *out_nvalid,
                              void *workspace, size_t workspace_bytes, void *stream) {
+    if (Nq == 0 && Nk >= 0 && C >= 1 && k >= 1) return DDG_OK;       // an empty query shard (its pointers may be NULL)
     if (!offsets_host || !out_code) return DDG_E_ARG;
     int rc = attn_check_dims(Nq, Nk, C, D, mode);
     if (rc) return rc;
@@ -2799,6 +2802,7 @@ extern "C" int ddg_attn_topk_fill(const float *Xq0, const uint8_t *mq, int64_t q
                                   const uint8_t *mk, const float *W, const int32_t *offsets_host, int64_t Nq,
                                   int64_t Nk, int C, int D, int64_t k, int mode, float *out_code, float *out_tau,
                                   int32_t *out_nvalid, void *workspace, size_t workspace_bytes, void *stream) {
+    if (Nq == 0 && Nk >= 0 && C >= 1 && k >= 1) return DDG_OK;       // an empty query shard (its pointers may be NULL)
     if (!out_code || k < 1) return DDG_E_ARG;
     int rc = ddg_attn_prepare(Xq0, mq, q_row_offset, Xk0, mk, W, offsets_host, Nq, Nk, C, D, k, mode, workspace,
                               workspace_bytes, stream);

@@ -91,16 +91,48 @@ def virtual_pieces(N: int, world: int, rank: int):
     return [(v, vb[v][0] - base, vb[v][1] - base) for v in range(rank * g, (rank + 1) * g) if vb[v][1] > vb[v][0]]
 
 
-def sharded_attn_fill(comm: Comm, backend, X0_local, m_local, W, layout, k: int, N_total: int, out=None):
-    """top-k attention fill of the local query rows against ALL rows (keys all-gathered)."""
+def work_balanced_bounds(m8: torch.Tensor, world: int):
+    """Row ranges of the ATTENTION fill's query shards with (nearly) equal work.  The fill computes one similarity per
+    (missing cell, key observed in that cell's column), so a row weighs sum over its missing columns of the number of
+    keys observed there; even row counts leave most ranks idle when the missing cells sit in a block of rows (Region
+    missingness, BASELINE configs[4]: every pair belongs to the ranks that own the rectangle's rows).  ``m8``: the WHOLE
+    [N, C] mask (one byte per cell: cheap to all-gather first).  Contiguous ranges that cover all rows; a range may be
+    empty.  The sampler keeps shard_bounds (its cost is per row and its draws are tied to the virtual shards)."""
+    N = m8.shape[0]
+    m = (m8 != 0)
+    nobs = m.sum(0, dtype=torch.int64)                                    # keys observed per column
+    w = ((~m).to(torch.int64) * nobs[None, :]).sum(1)                     # work per query row
+    c = torch.cumsum(w, 0)
+    total = int(c[-1].item()) if N else 0
+    if total == 0:
+        return _even_bounds(N, world)
+    targets = torch.tensor([total * r // world for r in range(1, world)], dtype=torch.int64, device=c.device)
+    cuts = [0] + (torch.searchsorted(c, targets, right=False) + 1).clamp_(max=N).tolist() + [N]
+    for i in range(1, len(cuts)):                                         # (monotone by construction; keep it explicit)
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def sharded_attn_fill(comm: Comm, backend, X0_local, m_local, W, layout, k: int, N_total: int, out=None,
+                      query_bounds=None):
+    """top-k attention fill against ALL rows.  Every rank contributes its shard_bounds rows (``X0_local``, ``m_local``) to
+    the all-gather of the keys.  Its queries are those same rows by default; with ``query_bounds`` (work_balanced_bounds:
+    tables whose missing cells are not spread over the rows) they are rows query_bounds[rank] of the gathered table, and
+    the result covers THOSE rows -- the key exchange stays an even all-gather whatever the query ranges are."""
     bounds = shard_bounds(N_total, comm.world)
     counts = [b - a for a, b in bounds]
-    lo = bounds[comm.rank][0]
-    if comm.on:
-        Xk = comm.all_gather_rows(X0_local, counts)
-        mk = comm.all_gather_rows(m_local, counts)
-        return backend.attn_topk_fill(X0_local, m_local, Xk, mk, W, layout, k, q_row_offset=lo, out=out)
-    return backend.attn_topk_fill(X0_local, m_local, X0_local, m_local, W, layout, k, out=out)
+    if not comm.on:
+        return backend.attn_topk_fill(X0_local, m_local, X0_local, m_local, W, layout, k, out=out)
+    Xk = comm.all_gather_rows(X0_local, counts)
+    mk = comm.all_gather_rows(m_local, counts)
+    lo, hi = bounds[comm.rank] if query_bounds is None else query_bounds[comm.rank]
+    if query_bounds is None:
+        Xq, mq = X0_local, m_local
+    else:
+        Xq, mq = Xk[lo:hi], mk[lo:hi]
+    if hi == lo:                                                      # no query on this rank
+        return out if out is not None else Xq.clone()
+    return backend.attn_topk_fill(Xq, mq, Xk, mk, W, layout, k, q_row_offset=lo, out=out)
 
 
 def _cut(a, lo, hi):

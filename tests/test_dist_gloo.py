@@ -126,7 +126,12 @@ def _worker_body(rank, world, port, q):
         X0 = torch.tensor(za["X"] * Mx)
         m8 = torch.tensor(za["data_m"].astype(np.uint8))
         code = ddist.sharded_attn_fill(comm, be, X0[alo:ahi], m8[alo:ahi], torch.tensor(za["W"]), la, int(za["k"]), Na)
-    q.put((rank, lo, hi, out.numpy(), alo, ahi, code.numpy()))
+        # the same fill with the queries sharded by work: the keys still come from the even shards, the result covers
+        # the rank's row range of work_balanced_bounds
+        qb = ddist.work_balanced_bounds(m8, world)
+        code_w = ddist.sharded_attn_fill(comm, be, X0[alo:ahi], m8[alo:ahi], torch.tensor(za["W"]), la, int(za["k"]), Na,
+                                         query_bounds=qb)
+    q.put((rank, lo, hi, out.numpy(), alo, ahi, code.numpy(), qb[rank][0], qb[rank][1], code_w.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,12 +152,16 @@ def test_sharded_sampler_and_attention_world2():
     z, T, _, _, _ = _case()
     za = np.load(os.path.join(ROOT, "tests", "golden", "attn_mixed257.npz"))
     covered = 0
-    for rank, lo, hi, out, alo, ahi, code in sorted(res, key=lambda r: r[0]):
+    covered_w = 0
+    for rank, lo, hi, out, alo, ahi, code, qlo, qhi, code_w in sorted(res, key=lambda r: r[0]):
         # sync-BN over the two shards == BatchNorm over the whole table (golden x0_hat of the reference)
         np.testing.assert_allclose(out, z["x0_hat"][lo:hi], rtol=0, atol=2e-5)
         np.testing.assert_allclose(code, za["new_code"][alo:ahi], rtol=0, atol=1e-5)
+        assert code_w.shape[0] == qhi - qlo
+        np.testing.assert_allclose(code_w, za["new_code"][qlo:qhi], rtol=0, atol=1e-5)
         covered += hi - lo
-    assert covered == z["x"].shape[0]
+        covered_w += qhi - qlo
+    assert covered == z["x"].shape[0] and covered_w == za["X"].shape[0]
 
 
 def test_shard_bounds_cover_rows():
@@ -180,3 +189,38 @@ def test_virtual_shards_partition_rows_identically_for_every_world_size():
             assert pieces == ref, (N, world)
     # a world size that does not divide 8: one piece per rank, the rank as its number
     assert ddist.virtual_pieces(100, 3, 1) == [(1, 0, 34)]
+
+
+def test_work_balanced_bounds_even_out_a_region_rectangle():
+    """Attention queries sharded by work (missing cells x observed keys of their column): contiguous ranges that cover all
+    rows; with the missing cells in one block of rows (Region missingness) every rank gets about the same work, where even
+    row counts would give it all to one or two ranks; with cells missing everywhere the ranges are close to even."""
+    from ddgani_amd import dist as ddist
+    g = torch.Generator().manual_seed(3)
+    N, C = 20000, 16
+
+    def work(m8, lo, hi):
+        m = m8 != 0
+        nobs = m.sum(0, dtype=torch.int64)
+        return int(((~m[lo:hi]).to(torch.int64) * nobs[None, :]).sum())
+    region = torch.ones(N, C, dtype=torch.uint8)
+    region[3000:5500, 4:12] = 0
+    mcar = (torch.rand(N, C, generator=g) < 0.7).to(torch.uint8)
+    for m8, name in ((region, "region"), (mcar, "mcar")):
+        for world in (1, 2, 4, 8):
+            b = ddist.work_balanced_bounds(m8, world)
+            assert len(b) == world and b[0][0] == 0 and b[-1][1] == N
+            assert all(b[r][1] == b[r + 1][0] for r in range(world - 1)) and all(lo <= hi for lo, hi in b)
+            ws = [work(m8, lo, hi) for lo, hi in b]
+            total = sum(ws)
+            assert total == work(m8, 0, N)
+            # every share within one row's largest possible work (C * N) per cut of the ideal one
+            assert max(ws) <= total / world + C * N and min(ws) >= total / world - 2 * C * N, (name, world, ws)
+        if name == "region":
+            even = [work(m8, lo, hi) for lo, hi in ddist.shard_bounds(N, 8)]
+            assert max(even) > 3 * total / 8                                   # what even row counts would do
+        else:
+            b = ddist.work_balanced_bounds(m8, 8)
+            assert all(abs((hi - lo) - N / 8) < 0.02 * N for lo, hi in b)
+    # nothing missing: even rows
+    assert ddist.work_balanced_bounds(torch.ones(64, 4, dtype=torch.uint8), 4) == [(0, 16), (16, 32), (32, 48), (48, 64)]
