@@ -20,22 +20,28 @@
 // generic small GEMM, one workgroup (four waves splitting the depth) per 32x32 tile of C:  C[m,n] = sum_k A(m,k) * B(k,n)
 // with element strides (sam, sak) / (sbk, sbn), so the same kernel serves NN, NT and TN.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gemm_small(const float *__restrict__ A, int64_t sam, int64_t sak,
-                                                     const float *__restrict__ B, int64_t sbk, int64_t sbn,
-                                                     float *__restrict__ Cm, int64_t ldc, int M, int N, int K) {
+struct SmallGemm {
+    const float *A; int64_t sam, sak;
+    const float *B; int64_t sbk, sbn;
+    float *C; int64_t ldc;
+    int M, N, K;
+};
+__device__ __forceinline__ void gemm_small_tile(const SmallGemm &g, float (*red)[32 * 33]) {
     // the four waves of a workgroup take a quarter of the depth each; the partial tiles are added in LDS in a fixed order
-    __shared__ float red[4][32 * 33];
+    const int M = g.M, N = g.N, K = g.K;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r32 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    if (m0 >= M || n0 >= N) return;                  // (a pair launch covers the larger of the two tile grids)
     const int m = m0 + r32, n = n0 + r32;
     const bool mok = m < M, nok = n < N;
-    const float *Ap = A + (int64_t)(mok ? m : 0) * sam;
-    const float *Bp = B + (int64_t)(nok ? n : 0) * sbn;
+    const float *Ap = g.A + (int64_t)(mok ? m : 0) * g.sam;
+    const float *Bp = g.B + (int64_t)(nok ? n : 0) * g.sbn;
+    const int64_t sak = g.sak, sbk = g.sbk;
     const int kper = ((K + 7) / 8) * 2;              // a multiple of 2
     const int kbeg = wid * kper, kend = min(K, kbeg + kper);
     f32x16 acc;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     int k = kbeg;
     for (; k + 16 <= kend; k += 16) {
         float a[8], b[8];
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void k_gemm_small(const float *__restrict__ A,
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int g = 0; g < 16; ++g) red[wid][((g & 3) + 8 * (g >> 2) + 4 * h) * 33 + r32] = acc[g];
+    for (int q = 0; q < 16; ++q) red[wid][((q & 3) + 8 * (q >> 2) + 4 * h) * 33 + r32] = acc[q];
     __syncthreads();
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     if (n0 + c < N) {
@@ -63,26 +69,55 @@ __global__ __launch_bounds__(256) void k_gemm_small(const float *__restrict__ A,
         for (int i = 0; i < 4; ++i) {
             const int rl = rg * 4 + i;
             if (m0 + rl < M)
-                Cm[(int64_t)(m0 + rl) * ldc + n0 + c] =
+                g.C[(int64_t)(m0 + rl) * g.ldc + n0 + c] =
                     (red[0][rl * 33 + c] + red[1][rl * 33 + c]) + (red[2][rl * 33 + c] + red[3][rl * 33 + c]);
         }
     }
+}
+__global__ __launch_bounds__(256) void k_gemm_small(SmallGemm g) {
+    __shared__ float red[4][32 * 33];
+    gemm_small_tile(g, red);
+}
+// two independent products in ONE launch (blockIdx.z picks): the weight gradient and the input gradient of a layer's
+// backward both start from dY; at B = 128 each is a 5 us kernel on a few CUs and a launch saved is a sixth of its cost.
+// Same arithmetic per output element as two k_gemm_small launches.
+__global__ __launch_bounds__(256) void k_gemm_small_pair(SmallGemm g0, SmallGemm g1) {
+    __shared__ float red[4][32 * 33];
+    if (blockIdx.z == 0) gemm_small_tile(g0, red);
+    else gemm_small_tile(g1, red);
 }
 
 static int gemm_small(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *Cm,
                       int64_t ldc, int M, int N, int K, hipStream_t s) {
     dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
-    k_gemm_small<<<grid, 256, 0, s>>>(A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K);
+    k_gemm_small<<<grid, 256, 0, s>>>(SmallGemm{A, sam, sak, B, sbk, sbn, Cm, ldc, M, N, K});
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+static int gemm_small_pair(const SmallGemm &g0, const SmallGemm &g1, hipStream_t s) {
+    const int nx = ((g0.N > g1.N ? g0.N : g1.N) + 31) / 32, ny = ((g0.M > g1.M ? g0.M : g1.M) + 31) / 32;
+    k_gemm_small_pair<<<dim3((unsigned)nx, (unsigned)ny, 2), 256, 0, s>>>(g0, g1);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
 // dA[B,in] = dY[B,out] * W[out,in]
+static SmallGemm op_dA(const float *dY, const float *W, float *dA, int rows, int in, int out) {
+    return SmallGemm{dY, out, 1, W, in, 1, dA, in, rows, in, out};
+}
+// dW[out,in] = dY[B,out]^T * H[B,in]
+static SmallGemm op_dW(const float *dY, const float *H, float *dW, int rows, int in, int out) {
+    return SmallGemm{dY, 1, out, H, in, 1, dW, in, out, in, rows};
+}
 static int gemm_dA(const float *dY, const float *W, float *dA, int rows, int in, int out, hipStream_t s) {
     return gemm_small(dY, out, 1, W, in, 1, dA, in, rows, in, out, s);
 }
-// dW[out,in] = dY[B,out]^T * H[B,in]
 static int gemm_dW(const float *dY, const float *H, float *dW, int rows, int in, int out, hipStream_t s) {
     return gemm_small(dY, 1, out, H, in, 1, dW, in, out, in, rows, s);
+}
+// both gradients of one layer's backward in one launch
+static int gemm_dW_dA(const float *dY, const float *H, float *dW, const float *W, float *dA, int rows, int in, int out,
+                      hipStream_t s) {
+    return gemm_small_pair(op_dW(dY, H, dW, rows, in, out), op_dA(dY, W, dA, rows, in, out), s);
 }
 
 // Column reductions over the B rows of a minibatch: a workgroup owns 32 columns, its 8 row slices (rows slice, slice + 8,
@@ -690,9 +725,8 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
     k_head_bwd<<<g256((int64_t)B * C), 256, 0, s>>>(ws.dres, w_res, ws.dcat, 2 * D, b->M, b->t, sched_dev, T, ws.pred,
                                                    offsets_dev, is_cat_dev, C, B, D, ws.dy, ws.lpart, losses_dev);
     // layer 4
-    if ((rc = gemm_dW(ws.dy, ws.h3, grads->W4, B, E, D, s))) return rc;
+    if ((rc = gemm_dW_dA(ws.dy, ws.h3, grads->W4, gw->W4, ws.dh, B, E, D, s))) return rc;
     k_colsum<<<gcol32(D), 256, 0, s>>>(ws.dy, B, D, grads->b4);
-    if ((rc = gemm_dA(ws.dy, gw->W4, ws.dh, B, E, D, s))) return rc;
     // layers 3, 2, 1
     const float *Wl[3] = {gw->W1, gw->W2, gw->W3}, *gl[3] = {gw->g1, gw->g2, gw->g3};
     float *dWl[3] = {grads->W1, grads->W2, grads->W3}, *dbl[3] = {grads->b1, grads->b2, grads->b3};
@@ -711,9 +745,8 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
             k_bn_act_bwd<<<gcol32(wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l],
                                                             ws.dz, dgl[l], dbel[l], dbl[l]);
         }
-        if ((rc = gemm_dW(ws.dz, hin[l], dWl[l], B, win[l], wout[l], s))) return rc;
+        if ((rc = gemm_dW_dA(ws.dz, hin[l], dWl[l], Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
         if (dp.ar) k_colsum<<<gcol32(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
-        if ((rc = gemm_dA(ws.dz, Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
     }
     k_emb_grad<<<dim3(gcol32(D), (unsigned)gw->n_steps), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
     if (pred_out && (rc = copy_f32_async(pred_out, ws.pred, (size_t)B * D, s))) return rc;
@@ -769,26 +802,23 @@ extern "C" int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc
     if (rc) return rc;
     k_disc_loss_grad<<<1, 1024, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 1, loss_scale, ws.da4, loss_dev);
     // layer 4
-    if ((rc = gemm_dW(ws.da4, ws.r3, grads->W4, B, H, C, s))) return rc;
+    if ((rc = gemm_dW_dA(ws.da4, ws.r3, grads->W4, dw->W4, ws.dA, B, H, C, s))) return rc;
     k_colsum<<<gcol32(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
-    if ((rc = gemm_dA(ws.da4, dw->W4, ws.dA, B, H, C, s))) return rc;
     // layer 3
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
     k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e3);
-    if ((rc = gemm_dW(ws.dB, ws.r2, grads->W3, B, H, H, s))) return rc;
+    if ((rc = gemm_dW_dA(ws.dB, ws.r2, grads->W3, dw->W3, ws.dA, B, H, H, s))) return rc;
     k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b3);
-    if ((rc = gemm_dA(ws.dB, dw->W3, ws.dA, B, H, H, s))) return rc;
     // layer 2
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r2, B * H, ws.dB);
     k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e2);
-    if ((rc = gemm_dW(ws.dB, ws.r1, grads->W2, B, H, H, s))) return rc;
+    if ((rc = gemm_dW_dA(ws.dB, ws.r1, grads->W2, dw->W2, ws.dA, B, H, H, s))) return rc;
     k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b2);
-    if ((rc = gemm_dA(ws.dB, dw->W2, ws.dA, B, H, H, s))) return rc;
     // layer 1: input = cat(xtj1, x_t)
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r1, B * H, ws.dB);
     k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e1);
-    if ((rc = gemm_small(ws.dB, 1, H, ws.xtj1, D, 1, grads->W1, 2 * D, H, D, B, s))) return rc;
-    if ((rc = gemm_small(ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B, s))) return rc;
+    if ((rc = gemm_small_pair(SmallGemm{ws.dB, 1, H, ws.xtj1, D, 1, grads->W1, 2 * D, H, D, B},
+                              SmallGemm{ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B}, s))) return rc;
     k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b1);
     if (pred_out && (rc = copy_f32_async(pred_out, ws.pred, (size_t)B * D, s))) return rc;
     DDG_CHECK_LAUNCH();
