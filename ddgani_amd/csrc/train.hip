@@ -81,10 +81,25 @@ __global__ __launch_bounds__(256) void k_gemm_small(SmallGemm g) {
 // two independent products in ONE launch (blockIdx.z picks): the weight gradient and the input gradient of a layer's
 // backward both start from dY; at B = 128 each is a 5 us kernel on a few CUs and a launch saved is a sixth of its cost.
 // Same arithmetic per output element as two k_gemm_small launches.
-__global__ __launch_bounds__(256) void k_gemm_small_pair(SmallGemm g0, SmallGemm g1) {
+// A third plane (blockIdx.z == 2, when cs.out is set) sums the columns of dY: the layer's bias gradient, k_colsum's code.
+struct ColSum { const float *X; int rows, N; float *out; };
+__global__ __launch_bounds__(256) void k_gemm_small_pair(SmallGemm g0, SmallGemm g1, ColSum cs) {
     __shared__ float red[4][32 * 33];
-    if (blockIdx.z == 0) gemm_small_tile(g0, red);
-    else gemm_small_tile(g1, red);
+    if (blockIdx.z == 0) { gemm_small_tile(g0, red); return; }
+    if (blockIdx.z == 1) { gemm_small_tile(g1, red); return; }
+    if (blockIdx.y != 0 || (int)blockIdx.x * 32 >= cs.N) return;
+    float(*r8)[32] = reinterpret_cast<float(*)[32]>(&red[0][0]);
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    float sum = 0.f;
+    if (col < cs.N)
+        for (int r = slice; r < cs.rows; r += 8) sum += cs.X[(int64_t)r * cs.N + col];
+    r8[slice][c] = sum;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += r8[j][c];
+    if (slice == 0 && col < cs.N) cs.out[col] = t;
 }
 
 static int gemm_small(const float *A, int64_t sam, int64_t sak, const float *B, int64_t sbk, int64_t sbn, float *Cm,
@@ -94,9 +109,11 @@ static int gemm_small(const float *A, int64_t sam, int64_t sak, const float *B, 
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
-static int gemm_small_pair(const SmallGemm &g0, const SmallGemm &g1, hipStream_t s) {
-    const int nx = ((g0.N > g1.N ? g0.N : g1.N) + 31) / 32, ny = ((g0.M > g1.M ? g0.M : g1.M) + 31) / 32;
-    k_gemm_small_pair<<<dim3((unsigned)nx, (unsigned)ny, 2), 256, 0, s>>>(g0, g1);
+static int gemm_small_pair(const SmallGemm &g0, const SmallGemm &g1, hipStream_t s, ColSum cs = ColSum{nullptr, 0, 0, nullptr}) {
+    int nmax = g0.N > g1.N ? g0.N : g1.N;
+    if (cs.out && cs.N > nmax) nmax = cs.N;
+    const int nx = (nmax + 31) / 32, ny = ((g0.M > g1.M ? g0.M : g1.M) + 31) / 32;
+    k_gemm_small_pair<<<dim3((unsigned)nx, (unsigned)ny, cs.out ? 3 : 2), 256, 0, s>>>(g0, g1, cs);
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
@@ -115,9 +132,10 @@ static int gemm_dW(const float *dY, const float *H, float *dW, int rows, int in,
     return gemm_small(dY, 1, out, H, in, 1, dW, in, out, in, rows, s);
 }
 // both gradients of one layer's backward in one launch
+// (db: the bias gradient = column sums of dY, or nullptr)
 static int gemm_dW_dA(const float *dY, const float *H, float *dW, const float *W, float *dA, int rows, int in, int out,
-                      hipStream_t s) {
-    return gemm_small_pair(op_dW(dY, H, dW, rows, in, out), op_dA(dY, W, dA, rows, in, out), s);
+                      hipStream_t s, float *db = nullptr) {
+    return gemm_small_pair(op_dW(dY, H, dW, rows, in, out), op_dA(dY, W, dA, rows, in, out), s, ColSum{dY, rows, out, db});
 }
 
 // Column reductions over the B rows of a minibatch: a workgroup owns 32 columns, its 8 row slices (rows slice, slice + 8,
@@ -725,8 +743,7 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
     k_head_bwd<<<g256((int64_t)B * C), 256, 0, s>>>(ws.dres, w_res, ws.dcat, 2 * D, b->M, b->t, sched_dev, T, ws.pred,
                                                    offsets_dev, is_cat_dev, C, B, D, ws.dy, ws.lpart, losses_dev);
     // layer 4
-    if ((rc = gemm_dW_dA(ws.dy, ws.h3, grads->W4, gw->W4, ws.dh, B, E, D, s))) return rc;
-    k_colsum<<<gcol32(D), 256, 0, s>>>(ws.dy, B, D, grads->b4);
+    if ((rc = gemm_dW_dA(ws.dy, ws.h3, grads->W4, gw->W4, ws.dh, B, E, D, s, grads->b4))) return rc;
     // layers 3, 2, 1
     const float *Wl[3] = {gw->W1, gw->W2, gw->W3}, *gl[3] = {gw->g1, gw->g2, gw->g3};
     float *dWl[3] = {grads->W1, grads->W2, grads->W3}, *dbl[3] = {grads->b1, grads->b2, grads->b3};
@@ -745,8 +762,7 @@ extern "C" int ddg_train_gen_grads_dp(const ddg_gen_weights *gw, const ddg_disc_
             k_bn_act_bwd<<<gcol32(wout[l]), 256, 0, s>>>(ws.dh, gt[l], zl[l], ws.st[l], gl[l], bn_eps, B, wout[l],
                                                             ws.dz, dgl[l], dbel[l], dbl[l]);
         }
-        if ((rc = gemm_dW_dA(ws.dz, hin[l], dWl[l], Wl[l], ws.dh, B, win[l], wout[l], s))) return rc;
-        if (dp.ar) k_colsum<<<gcol32(wout[l]), 256, 0, s>>>(ws.dz, B, wout[l], dbl[l]);
+        if ((rc = gemm_dW_dA(ws.dz, hin[l], dWl[l], Wl[l], ws.dh, B, win[l], wout[l], s, dp.ar ? dbl[l] : nullptr))) return rc;
     }
     k_emb_grad<<<dim3(gcol32(D), (unsigned)gw->n_steps), 256, 0, s>>>(ws.dh, D, b->t, B, D, gw->n_steps, grads->temb);
     if (pred_out && (rc = copy_f32_async(pred_out, ws.pred, (size_t)B * D, s))) return rc;
@@ -802,24 +818,21 @@ extern "C" int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc
     if (rc) return rc;
     k_disc_loss_grad<<<1, 1024, 0, s>>>(ws.a4, b->m, B * C, dp.Bg * C, 1, loss_scale, ws.da4, loss_dev);
     // layer 4
-    if ((rc = gemm_dW_dA(ws.da4, ws.r3, grads->W4, dw->W4, ws.dA, B, H, C, s))) return rc;
-    k_colsum<<<gcol32(C), 256, 0, s>>>(ws.da4, B, C, grads->b4);
+    if ((rc = gemm_dW_dA(ws.da4, ws.r3, grads->W4, dw->W4, ws.dA, B, H, C, s, grads->b4))) return rc;
     // layer 3
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r3, B * H, ws.dB);
     k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e3);
-    if ((rc = gemm_dW_dA(ws.dB, ws.r2, grads->W3, dw->W3, ws.dA, B, H, H, s))) return rc;
-    k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b3);
+    if ((rc = gemm_dW_dA(ws.dB, ws.r2, grads->W3, dw->W3, ws.dA, B, H, H, s, grads->b3))) return rc;
     // layer 2
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r2, B * H, ws.dB);
     k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e2);
-    if ((rc = gemm_dW_dA(ws.dB, ws.r1, grads->W2, dw->W2, ws.dA, B, H, H, s))) return rc;
-    k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b2);
+    if ((rc = gemm_dW_dA(ws.dB, ws.r1, grads->W2, dw->W2, ws.dA, B, H, H, s, grads->b2))) return rc;
     // layer 1: input = cat(xtj1, x_t)
     k_relu_bwd<<<g256((int64_t)B * H), 256, 0, s>>>(ws.dA, ws.r1, B * H, ws.dB);
     k_emb_grad<<<dim3(gcol32(H), (unsigned)dw->n_steps), 256, 0, s>>>(ws.dB, H, b->t, B, H, dw->n_steps, grads->e1);
     if ((rc = gemm_small_pair(SmallGemm{ws.dB, 1, H, ws.xtj1, D, 1, grads->W1, 2 * D, H, D, B},
-                              SmallGemm{ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B}, s))) return rc;
-    k_colsum<<<gcol32(H), 256, 0, s>>>(ws.dB, B, H, grads->b1);
+                              SmallGemm{ws.dB, 1, H, ws.xt, D, 1, grads->W1 + D, 2 * D, H, D, B}, s,
+                              ColSum{ws.dB, B, H, grads->b1}))) return rc;
     if (pred_out && (rc = copy_f32_async(pred_out, ws.pred, (size_t)B * D, s))) return rc;
     DDG_CHECK_LAUNCH();
     return DDG_OK;
