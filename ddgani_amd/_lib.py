@@ -111,6 +111,9 @@ SIGNATURES = {
                                           C.POINTER(DiscGrads), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.POINTER(Dp)]),
     "ddg_set_stream_offset": (C.c_int, [C.c_void_p]),
+    "ddg_gather_batch": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p,
+                                   c_f32p, c_i64p, c_i64p, C.c_void_p]),
+    "ddg_step_end": (C.c_int, [c_i64p, c_i64p, C.c_void_p]),
     "ddg_adam_step": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, C.c_double, C.c_double,
                                 C.c_double, C.c_double, C.c_double, C.c_void_p]),

@@ -1206,3 +1206,48 @@ extern "C" int ddg_dplain_fwd(const ddg_dplain_weights *w, const float *x, const
     DDG_CHECK_LAUNCH();
     return DDG_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// The minibatch gather of a training step (sample_x's x[rows, :], utils/util.py:582-585, applied to the encoded table, its
+// expanded mask and the [N, C] mask) in ONE launch, and the book-keeping of a step that is replayed as a captured graph:
+// counter -> offset before the step's first draw, counter += 2^32 and offset = 0 after its last (ddg_set_stream_offset).
+// Row indices are clamped into the table (torch would raise).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gather_batch(const float *__restrict__ x, const float *__restrict__ M, const float *__restrict__ m,
+                               const int64_t *__restrict__ idx, int64_t n_rows, int B, int D, int C,
+                               float *__restrict__ x0, float *__restrict__ Mb, float *__restrict__ mb,
+                               const int64_t *__restrict__ counter, int64_t *__restrict__ offset) {
+    if (offset && blockIdx.x == 0 && threadIdx.x == 0) offset[0] = counter[0];
+    const int per = 2 * D + C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)B * per; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e / per), j = (int)(e - (int64_t)r * per);
+        int64_t row = idx[r];
+        row = row < 0 ? 0 : (row >= n_rows ? n_rows - 1 : row);
+        if (j < D) x0[(int64_t)r * D + j] = x[row * D + j];
+        else if (j < 2 * D) Mb[(int64_t)r * D + j - D] = M[row * D + j - D];
+        else mb[(int64_t)r * C + j - 2 * D] = m[row * C + j - 2 * D];
+    }
+}
+__global__ void k_step_end(int64_t *__restrict__ counter, int64_t *__restrict__ offset) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { counter[0] += (int64_t)1 << 32; offset[0] = 0; }
+}
+
+extern "C" int ddg_gather_batch(const float *x, const float *M, const float *m, const int64_t *idx, int64_t n_rows, int B,
+                                int D, int C, float *x0, float *Mb, float *mb, const int64_t *counter, int64_t *offset,
+                                void *stream) {
+    if (!x || !M || !m || !idx || !x0 || !Mb || !mb || n_rows < 1 || B < 1 || D < 1 || C < 1) return DDG_E_ARG;
+    if ((counter == nullptr) != (offset == nullptr)) return DDG_E_ARG;
+    const int64_t n = (int64_t)B * (2 * D + C);
+    k_gather_batch<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, M, m, idx, n_rows, B, D, C, x0, Mb, mb,
+                                                                               counter, offset);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}
+
+extern "C" int ddg_step_end(int64_t *counter, int64_t *offset, void *stream) {
+    if (!counter || !offset) return DDG_E_ARG;
+    k_step_end<<<1, 64, 0, (hipStream_t)stream>>>(counter, offset);
+    DDG_CHECK_LAUNCH();
+    return DDG_OK;
+}

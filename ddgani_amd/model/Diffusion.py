@@ -327,6 +327,9 @@ class GraphedSteps:
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)             # replays so far << 32
         self.offset = torch.zeros(1, dtype=torch.int64, device=device)              # what the library adds: 0 outside a step
         self.graphs = {}
+        self.batch = (torch.empty((self.B, x.shape[1]), dtype=torch.float32, device=device),
+                      torch.empty((self.B, x.shape[1]), dtype=torch.float32, device=device),
+                      torch.empty((self.B, m_data.shape[1]), dtype=torch.float32, device=device))
         ops.set_stream_offset(self.offset)
         GraphedSteps._owner = weakref.ref(self)
 
@@ -354,12 +357,12 @@ class GraphedSteps:
                                                                        self.m.data_ptr(), self.T)
 
     def _body(self, fn):
-        torch.add(self.counter, 0, out=self.offset)          # (arithmetic kernels: no memcpy / memset node in the graph)
+        # one launch: counter -> offset, then the three gathers of the batch (kernels only: no memcpy / memset node in the
+        # graph); one more after the step: counter += 2^32, offset = 0
         idx, t = self.feed[:self.B], self.feed[self.B:]
-        x0, Mb, mb = self.x.index_select(0, idx), self.M.index_select(0, idx), self.m.index_select(0, idx)
+        x0, Mb, mb = ops.gather_batch(self.x, self.M, self.m, idx, out=self.batch, counter=self.counter, offset=self.offset)
         loss = fn(x0, Mb, mb, t)
-        self.counter.add_(1 << 32)
-        self.offset.mul_(0)
+        ops.step_end(self.counter, self.offset)
         return loss
 
     def step(self, key, fn, rnd):

@@ -46,6 +46,23 @@ def set_stream_offset(counter: Optional[torch.Tensor]):
     check(lib().ddg_set_stream_offset(_ptr(counter)), "ddg_set_stream_offset")
 
 
+def gather_batch(x, M, m, idx, out=None, counter=None, offset=None):
+    """ddg_gather_batch: (x[idx], M[idx], m[idx]) in one launch; ``out``: the three preallocated destinations;
+    counter / offset: the captured step's stream-offset words (see model.Diffusion.GraphedSteps)."""
+    B, D, Cn = idx.numel(), x.shape[1], m.shape[1]
+    if out is None:
+        out = (torch.empty((B, D), dtype=torch.float32, device=x.device), torch.empty((B, D), dtype=torch.float32, device=x.device),
+               torch.empty((B, Cn), dtype=torch.float32, device=x.device))
+    check(lib().ddg_gather_batch(_ptr(x, torch.float32), _ptr(M, torch.float32), _ptr(m, torch.float32), _ptr(idx, torch.int64),
+                                 x.shape[0], B, D, Cn, _ptr(out[0], torch.float32), _ptr(out[1], torch.float32),
+                                 _ptr(out[2], torch.float32), _ptr(counter), _ptr(offset), _stream()), "ddg_gather_batch")
+    return out
+
+
+def step_end(counter, offset):
+    check(lib().ddg_step_end(_ptr(counter), _ptr(offset), _stream()), "ddg_step_end")
+
+
 class FieldLayout:
     """Encoded-column layout of a table: column c occupies [offsets[c], offsets[c+1])."""
 

@@ -300,6 +300,16 @@ int ddg_train_disc_grads_dp(const ddg_gen_weights *gw, const ddg_disc_weights *d
                             float *pred_out, void *workspace, size_t workspace_bytes, void *stream,
                             const ddg_dp *dp);
 
+/* The minibatch gather of a training step in one launch: x0 = x[idx], Mb = M[idx] ([B, D]), mb = m[idx] ([B, C]) --
+ * sample_x's x[rows, :] (utils/util.py:582-585; model/Diffusion.py:287-289, 356-358 index the table, the expanded mask
+ * and the [N, C] mask with the same rows).  idx: int64[B] on the device, clamped into [0, n_rows).  counter / offset
+ * (both or neither; no reference counterpart): the book-keeping of a step replayed as a captured graph -- offset[0] =
+ * counter[0] before the step's first on-chip draw (see ddg_set_stream_offset); ddg_step_end adds 2^32 to the counter
+ * and clears the offset after its last. */
+int ddg_gather_batch(const float *x, const float *M, const float *m, const int64_t *idx, int64_t n_rows, int B, int D,
+                     int C, float *x0, float *Mb, float *mb, const int64_t *counter, int64_t *offset, void *stream);
+int ddg_step_end(int64_t *counter, int64_t *offset, void *stream);
+
 /* host arrays of n_tensors (<= 16) device pointers; step counts from 1 */
 int ddg_adam_step(int n_tensors, float *const *params, const float *const *grads, float *const *exp_avg,
                   float *const *exp_avg_sq, const int64_t *numel, int step, double lr, double beta1,
